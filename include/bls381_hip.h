@@ -1,0 +1,138 @@
+/* C ABI of the MI355X (gfx950) batched BLS12-381 pairing engine.
+ *
+ * The reference (a Rust crate) has no FFI of its own; its boundary is the public Rust API of
+ * src/native/.  Each entry point below names the Rust item it replaces.  A Rust caller keeps the
+ * reference's signatures and forwards to these functions (binding sketch: INTEGRATION.md).
+ *
+ * Data layouts (all little-endian):
+ *   Fq    6 x u64, Montgomery form with R = 2^384: the in-memory limbs of ark_ff's Fq
+ *         (BigInt<6>), so no conversion happens on either side.
+ *   G1    {x, y}                      12 u64  (affine; infinity is carried by inf_flags)
+ *   G2    {x.c0, x.c1, y.c0, y.c1}    24 u64
+ *   Fq12  72 u64 in ark tower order   c0.c0.c0, c0.c0.c1, c0.c1.c0, ..., c1.c2.c1
+ *   inf_flags  one byte per pair: bit 0 = P is infinity, bit 1 = Q is infinity (may be NULL)
+ *   "limbs" entry points use the circuit's witness format instead: canonical (non-Montgomery)
+ *   values, 12 x u32 little-endian per Fq (src/fields/fq_target.rs:280-293), Fq12 as 12 Fq in
+ *   MyFq12 (w-power) order (src/utils/helpers.rs:14-44).
+ *
+ * Every function returns 0 on success and a negative code on failure; bls381_last_error() gives a
+ * thread-local message.  Nothing aborts or throws across this boundary.  A context is bound to
+ * one GPU; calls on one context are serialised internally, so it may be shared by host threads.
+ * Buffers are caller-owned host memory unless the name ends in _dev (device memory on the
+ * context's GPU, for callers that keep data resident in HBM).
+ */
+#ifndef BLS381_HIP_H
+#define BLS381_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bls381_ctx bls381_ctx;
+
+enum {
+    BLS381_OK = 0,
+    BLS381_ERR_INVALID = -1,   /* bad argument (NULL pointer, n too large, ...) */
+    BLS381_ERR_NO_DEVICE = -2, /* no usable gfx950 device / HIP runtime failure at start-up */
+    BLS381_ERR_HIP = -3,       /* a HIP call failed; see bls381_last_error() */
+    BLS381_ERR_ZERO = -4,      /* an input that the reference rejects by panicking (zero divisor) */
+};
+
+/* Creates a context on HIP device `device_id`.  Builds and uploads the step programs. */
+int bls381_ctx_create(bls381_ctx** out, int device_id);
+/* Same, choosing the lane-group width K (6, 8, 9, 12 or 16 lanes per pairing) and the number of
+ * LDS slots per group; 0 selects the defaults. */
+int bls381_ctx_create_ex(bls381_ctx** out, int device_id, int lanes_per_group, int lds_slots);
+void bls381_ctx_destroy(bls381_ctx* ctx);
+const char* bls381_last_error(void);
+
+/* multi_miller_loop_native([G1Prepared(p)], [G2Prepared::from(q)]) for each of n independent
+ * pairs (src/native/miller_loop.rs:121-162).  A pair with an infinity flag yields Fq12::ONE,
+ * as the reference's filter at :130-136 does. */
+int bls381_miller_loop_batch(bls381_ctx*, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf_flags,
+                             size_t n, uint64_t* out_fq12);
+/* final_exponentiation (src/native/final_exponentiation.rs:74-78) of n Fq12 values given in ark
+ * order.  is_zero_err (may be NULL) receives 1 for an item equal to zero, on which the reference
+ * panics (division at :13); such an item's output is unspecified. Returns BLS381_ERR_ZERO if any. */
+int bls381_final_exp_batch(bls381_ctx*, const uint64_t* in_fq12, size_t n, uint64_t* out_fq12,
+                           uint8_t* is_zero_err);
+/* native_pairing([p], [q]) for each of n independent pairs (src/native/pairing.rs:8-13). */
+int bls381_pairing_batch(bls381_ctx*, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf_flags, size_t n,
+                         uint64_t* out_fq12);
+/* multi_miller_loop_native over all n pairs at once: one Fq12 (src/native/miller_loop.rs:121-162;
+ * the product over chunks at :155 equals the product of the per-pair values). */
+int bls381_multi_miller_loop(bls381_ctx*, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf_flags,
+                             size_t n_pairs, uint64_t out_fq12[72]);
+/* native_pairing over all n pairs: final_exponentiation of the above.  *is_one = 1 iff the result
+ * is Fq12::ONE (the aggregate-signature check). */
+int bls381_multi_pairing(bls381_ctx*, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf_flags,
+                         size_t n_pairs, uint64_t out_fq12[72], int* is_one);
+/* Product of per-rank partial Miller values followed by the final exponentiation: the step after
+ * the gather in a multi-GPU multi-pairing.  partials: n_partials x 72 u64. */
+int bls381_finish_multi_pairing(bls381_ctx*, const uint64_t* partials, size_t n_partials, uint64_t out_fq12[72],
+                                int* is_one);
+/* G2Prepared::from(q).ell_coeffs for n points (src/native/miller_loop.rs:90-119):
+ * out_coeffs = n x 68 x 3 Fq2 = n x 68 x 36 u64. */
+int bls381_g2_prepare_batch(bls381_ctx*, const uint64_t* g2, size_t n, uint64_t* out_coeffs);
+/* ell(f, coeffs, p) (src/native/miller_loop.rs:185-194) for n independent triples.
+ * f: n x 72 u64 (in and out), coeffs: n x 36 u64, g1: n x 12 u64. */
+int bls381_ell_batch(bls381_ctx*, const uint64_t* f_in, const uint64_t* coeffs, const uint64_t* g1, size_t n,
+                     uint64_t* f_out);
+/* easy_part_native (src/native/final_exponentiation.rs:8-19) and hard_part_native (:44-72, any
+ * Fq12, generic squarings) as separate batch calls; ark order in and out. */
+int bls381_easy_part_batch(bls381_ctx*, const uint64_t* in_fq12, size_t n, uint64_t* out_fq12, uint8_t* is_zero_err);
+int bls381_hard_part_batch(bls381_ctx*, const uint64_t* in_fq12, size_t n, uint64_t* out_fq12);
+/* frobenius_map_native(a, power), power in {1, 2} (src/native/fin_exp_helpers.rs:10-47). */
+int bls381_frobenius_batch(bls381_ctx*, const uint64_t* in_fq12, int power, size_t n, uint64_t* out_fq12);
+/* Fq12 product (ark Fq12 `*`, equal to MyFq12::mul, src/utils/helpers.rs:90-152). */
+int bls381_fq12_mul_batch(bls381_ctx*, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out_fq12);
+
+/* Fq12InverseGenerator::run_once (src/fields/fq12_target.rs:374-397) for n values:
+ * x and inv are n x 144 u32 canonical limbs in MyFq12 order.  err (may be NULL): per item,
+ * 1 = a limb-decoded coefficient >= p, 2 = x is zero (both panic in the reference). */
+int bls381_fq12_inverse_limbs_batch(bls381_ctx*, const uint32_t* x, size_t n, uint32_t* inv, uint8_t* err);
+
+/* Witness trace of the single-pair pairing circuit (src/pairing.rs:13-20 after
+ * G2PreparedTarget::from, src/curves/g2.rs:148-178): the value of every non-native Fq operation
+ * in builder call order, plus the 12 values written by Fq12InverseGenerator at the point where
+ * Fq12Target::inv is called.  Rows are 12 x u32 canonical limbs.
+ *   bls381_pairing_witness_rows()  number of rows per proof (141,376)
+ *   bls381_pairing_witness_kinds() fills kinds[rows]: 0 add, 1 sub, 2 mul, 3 neg, 4 inv, 5 generator output
+ *   trace: n_proofs x rows x 12 u32 */
+size_t bls381_pairing_witness_rows(void);
+int bls381_pairing_witness_kinds(uint8_t* kinds, size_t capacity);
+int bls381_pairing_witness_batch(bls381_ctx*, const uint64_t* g1, const uint64_t* g2, size_t n_proofs, uint32_t* trace);
+
+/* Device-resident variants: all pointers are device memory on the context's GPU; they run on the
+ * context's stream and return after the work has completed. */
+int bls381_pairing_batch_dev(bls381_ctx*, const uint64_t* g1_dev, const uint64_t* g2_dev, const uint8_t* inf_flags_dev,
+                             size_t n, uint64_t* out_fq12_dev);
+int bls381_miller_loop_batch_dev(bls381_ctx*, const uint64_t* g1_dev, const uint64_t* g2_dev,
+                                 const uint8_t* inf_flags_dev, size_t n, uint64_t* out_fq12_dev);
+int bls381_final_exp_batch_dev(bls381_ctx*, const uint64_t* in_fq12_dev, size_t n, uint64_t* out_fq12_dev,
+                               uint8_t* is_zero_err_dev);
+
+/* Introspection used by the tests and the benchmark. */
+/* Builds and schedules the step program `which` ("miller", "fe1", "fe2", "g2prep", "ell", "fq12mul",
+ * "easy2", "hardgen", "inv1", "inv2", "frob1", "frob2") for groups of K lanes and copies it into
+ * caller buffers: hdrs = nsteps x 2 u32, descs = nsteps x K x 8 u32.  info[8] receives
+ * {K, nsteps, lds_slots, tmp_slots, n_in, n_out, n_fmul, n_lin}.  Pass NULL buffers to query sizes.
+ * Host-only: needs no GPU. */
+int bls381_debug_program(const char* which, int lanes_per_group, int lds_slots, uint32_t* hdrs, uint32_t* descs,
+                         size_t capacity_steps, uint32_t info[8]);
+/* Constant table (C_COUNT x 12 u32). */
+int bls381_debug_constants(uint32_t* out, size_t capacity_fp);
+/* Timing of the most recent batch call on this context, from HIP events on the context's stream:
+ * ms[0] = Miller kernel, ms[1] = final-exponentiation kernels (incl. inversion), ms[2] = whole call
+ * on the device including layout conversion. */
+int bls381_last_timing(bls381_ctx*, float ms[3]);
+/* Sustained v_mad_u64_u32 rate of the device in multiply-accumulates per second (calibration kernel). */
+int bls381_calibrate_mac_rate(bls381_ctx*, double* mac_per_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLS381_HIP_H */

@@ -1,0 +1,80 @@
+"""ctypes loader for libbls381_hip.so (the C ABI declared in include/bls381_hip.h).
+
+The library is built in-tree by __graft_entry__.build() / `make -C plonky2_bls12_381_pairing_amd/csrc`.
+There is no CPU implementation behind these bindings: without the shared library the import fails,
+and without a gfx950 device every compute call returns an error.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbls381_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libbls381_hip.so is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+
+lib = C.CDLL(LIB_PATH)
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+ctxp = C.c_void_p
+
+def _sig(name, restype, *argtypes):
+    f = getattr(lib, name)
+    f.restype = restype
+    f.argtypes = list(argtypes)
+    return f
+
+_sig("bls381_ctx_create", C.c_int, C.POINTER(ctxp), C.c_int)
+_sig("bls381_ctx_create_ex", C.c_int, C.POINTER(ctxp), C.c_int, C.c_int, C.c_int)
+_sig("bls381_ctx_destroy", None, ctxp)
+_sig("bls381_last_error", C.c_char_p)
+_sig("bls381_miller_loop_batch", C.c_int, ctxp, u64p, u64p, u8p, C.c_size_t, u64p)
+_sig("bls381_final_exp_batch", C.c_int, ctxp, u64p, C.c_size_t, u64p, u8p)
+_sig("bls381_pairing_batch", C.c_int, ctxp, u64p, u64p, u8p, C.c_size_t, u64p)
+_sig("bls381_multi_miller_loop", C.c_int, ctxp, u64p, u64p, u8p, C.c_size_t, u64p)
+_sig("bls381_multi_pairing", C.c_int, ctxp, u64p, u64p, u8p, C.c_size_t, u64p, C.POINTER(C.c_int))
+_sig("bls381_finish_multi_pairing", C.c_int, ctxp, u64p, C.c_size_t, u64p, C.POINTER(C.c_int))
+_sig("bls381_g2_prepare_batch", C.c_int, ctxp, u64p, C.c_size_t, u64p)
+_sig("bls381_ell_batch", C.c_int, ctxp, u64p, u64p, u64p, C.c_size_t, u64p)
+_sig("bls381_easy_part_batch", C.c_int, ctxp, u64p, C.c_size_t, u64p, u8p)
+_sig("bls381_hard_part_batch", C.c_int, ctxp, u64p, C.c_size_t, u64p)
+_sig("bls381_frobenius_batch", C.c_int, ctxp, u64p, C.c_int, C.c_size_t, u64p)
+_sig("bls381_fq12_mul_batch", C.c_int, ctxp, u64p, u64p, C.c_size_t, u64p)
+_sig("bls381_fq12_inverse_limbs_batch", C.c_int, ctxp, u32p, C.c_size_t, u32p, u8p)
+_sig("bls381_pairing_witness_rows", C.c_size_t)
+_sig("bls381_pairing_witness_kinds", C.c_int, u8p, C.c_size_t)
+_sig("bls381_pairing_witness_batch", C.c_int, ctxp, u64p, u64p, C.c_size_t, u32p)
+_sig("bls381_pairing_batch_dev", C.c_int, ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+_sig("bls381_miller_loop_batch_dev", C.c_int, ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+_sig("bls381_final_exp_batch_dev", C.c_int, ctxp, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
+_sig("bls381_debug_program", C.c_int, C.c_char_p, C.c_int, C.c_int, u32p, u32p, C.c_size_t, u32p)
+_sig("bls381_debug_constants", C.c_int, u32p, C.c_size_t)
+_sig("bls381_last_timing", C.c_int, ctxp, C.POINTER(C.c_float))
+_sig("bls381_calibrate_mac_rate", C.c_int, ctxp, C.POINTER(C.c_double))
+
+# every symbol include/bls381_hip.h declares
+EXPORTED = [
+    "bls381_ctx_create", "bls381_ctx_create_ex", "bls381_ctx_destroy", "bls381_last_error",
+    "bls381_miller_loop_batch", "bls381_final_exp_batch", "bls381_pairing_batch", "bls381_multi_miller_loop",
+    "bls381_multi_pairing", "bls381_finish_multi_pairing", "bls381_g2_prepare_batch", "bls381_ell_batch",
+    "bls381_easy_part_batch", "bls381_hard_part_batch", "bls381_frobenius_batch", "bls381_fq12_mul_batch",
+    "bls381_fq12_inverse_limbs_batch", "bls381_pairing_witness_rows", "bls381_pairing_witness_kinds",
+    "bls381_pairing_witness_batch", "bls381_pairing_batch_dev", "bls381_miller_loop_batch_dev",
+    "bls381_final_exp_batch_dev", "bls381_debug_program", "bls381_debug_constants", "bls381_last_timing",
+    "bls381_calibrate_mac_rate",
+]
+
+
+class Bls381Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("bls381 error %d: %s" % (code, msg))
+        self.code = code
+
+
+def check(rc):
+    if rc != 0:
+        raise Bls381Error(rc, lib.bls381_last_error().decode())

@@ -1,0 +1,733 @@
+// C ABI (include/bls381_hip.h): context, program upload, batch entry points.
+#include "../../include/bls381_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "bls381_constants.h"
+#include "tape.h"
+#include "vm_kernels.h"
+#include "witness.h"
+
+using namespace bls381;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(x)                                                                                      \
+    do {                                                                                               \
+        hipError_t e_ = (x);                                                                           \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(BLS381_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));               \
+    } while (0)
+
+extern "C" const char* bls381_last_error(void) { return g_err.c_str(); }
+
+// ------------------------------------------------------------------ constant tables
+static void fill_constants(std::vector<uint32_t>& c) {
+    c.assign((size_t)C_COUNT * 12, 0);
+    auto put = [&](int id, const uint32_t* v) { std::memcpy(&c[(size_t)id * 12], v, 48); };
+    put(C_ONE, BLS381_ONE_MONT);
+    put(C_TWO_INV, BLS381_TWO_INV_MONT);
+    const uint32_t* f1[5][2] = {{BLS381_FROB1_1_C0, BLS381_FROB1_1_C1}, {BLS381_FROB1_2_C0, BLS381_FROB1_2_C1},
+                                {BLS381_FROB1_3_C0, BLS381_FROB1_3_C1}, {BLS381_FROB1_4_C0, BLS381_FROB1_4_C1},
+                                {BLS381_FROB1_5_C0, BLS381_FROB1_5_C1}};
+    const uint32_t* f2[5] = {BLS381_FROB2_1_C0, BLS381_FROB2_2_C0, BLS381_FROB2_3_C0, BLS381_FROB2_4_C0,
+                             BLS381_FROB2_5_C0};
+    for (int i = 0; i < 5; i++) {
+        put(C_FROB1_BASE + 2 * i, f1[i][0]);
+        put(C_FROB1_BASE + 2 * i + 1, f1[i][1]);
+        put(C_FROB2_BASE + i, f2[i]);
+    }
+    put(C_R2, BLS381_R2);
+    uint32_t one[12] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    put(C_RAW_ONE, one);
+}
+static void fill_kp(std::vector<uint32_t>& t) {
+    t.assign((size_t)KP_ROWS * 16, 0);
+    for (int k = 1; k < KP_ROWS; k++) {
+        uint64_t c = 0;
+        for (int i = 0; i < 13; i++) {
+            uint64_t s = (uint64_t)t[(size_t)(k - 1) * 16 + i] + BLS381_P1X[i] + c;
+            t[(size_t)k * 16 + i] = (uint32_t)s;
+            c = s >> 32;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ programs
+static Dag build_named(const std::string& which) {
+    if (which == "miller") return build_miller();
+    if (which == "g2prep") return build_g2_prepare();
+    if (which == "ell") return build_ell();
+    if (which == "fe1") return build_final_exp_part1();
+    if (which == "fe2") return build_final_exp_part2(true);
+    if (which == "easy2") return build_easy_part2();
+    if (which == "hardgen") return build_hard_part_generic();
+    if (which == "inv1") return build_fq12_inv_limbs_part1();
+    if (which == "inv2") return build_fq12_inv_limbs_part2();
+    if (which == "fq12mul") return build_fq12_mul();
+    if (which == "frob1") return build_frobenius(1);
+    if (which == "frob2") return build_frobenius(2);
+    throw std::runtime_error("unknown program " + which);
+}
+static const char* ALL_PROGRAMS[] = {"miller", "g2prep", "ell",  "fe1",     "fe2",   "easy2",
+                                     "hardgen", "inv1",   "inv2", "fq12mul", "frob1", "frob2"};
+
+static bool valid_k(int K) { return K == 6 || K == 8 || K == 9 || K == 12 || K == 16; }
+static int default_slots(int K) {
+    // 2 workgroups of 256 threads per CU: 160 KiB / 2 minus the k*p table, 48 bytes per slot and group
+    int gpw = 4 * (64 / K);
+    int s = (80 * 1024 - KP_ROWS * 64 - 256) / (48 * gpw);
+    return std::min(s, 120);
+}
+
+struct DevProgram {
+    Program host;
+    StepHdr* d_hdrs = nullptr;
+    OpDesc* d_descs = nullptr;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; bytes = 0; }
+        size_t want = need + need / 8;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return e;
+        bytes = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct bls381_ctx {
+    int device = 0;
+    int K = 8;
+    int lds_slots = 0;
+    hipStream_t stream = nullptr;
+    std::map<std::string, DevProgram> progs;
+    uint4* d_consts = nullptr;
+    uint4* d_kp = nullptr;
+    DevBuf user_in, user_in2, user_in3, user_out, flags, bufA, bufB, bufC, bufTmp, zflags;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float last_ms[3] = {0, 0, 0};
+    std::mutex mu;
+    // witness machinery (built lazily)
+    WitnessDevice wit;
+};
+
+static int upload_program(bls381_ctx* c, const std::string& which) {
+    DevProgram dp;
+    try {
+        dp.host = schedule(build_named(which), c->K, c->lds_slots, which);
+    } catch (std::exception& e) {
+        return fail(BLS381_ERR_INVALID, std::string("program ") + which + ": " + e.what());
+    }
+    HIPCHK(hipMalloc((void**)&dp.d_hdrs, dp.host.hdrs.size() * sizeof(StepHdr)));
+    HIPCHK(hipMalloc((void**)&dp.d_descs, dp.host.descs.size() * sizeof(OpDesc)));
+    HIPCHK(hipMemcpy(dp.d_hdrs, dp.host.hdrs.data(), dp.host.hdrs.size() * sizeof(StepHdr), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dp.d_descs, dp.host.descs.data(), dp.host.descs.size() * sizeof(OpDesc), hipMemcpyHostToDevice));
+    c->progs[which] = dp;
+    return 0;
+}
+
+extern "C" int bls381_ctx_create_ex(bls381_ctx** out, int device_id, int K, int lds_slots) {
+    if (!out) return fail(BLS381_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (K == 0) K = 8;
+    if (!valid_k(K)) return fail(BLS381_ERR_INVALID, "lanes_per_group must be 6, 8, 9, 12 or 16");
+    if (lds_slots == 0) lds_slots = default_slots(K);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(BLS381_ERR_NO_DEVICE, "no HIP device available");
+    if (device_id < 0 || device_id >= ndev) return fail(BLS381_ERR_INVALID, "device_id out of range");
+    HIPCHK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        return fail(BLS381_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950");
+    size_t lds_bytes = (size_t)lds_slots * 48 * (4 * (64 / K)) + KP_ROWS * 64;
+    if (lds_bytes > 160 * 1024) return fail(BLS381_ERR_INVALID, "lds_slots does not fit the 160 KiB LDS");
+    bls381_ctx* c = new bls381_ctx();
+    c->device = device_id; c->K = K; c->lds_slots = lds_slots;
+    int rc = 0;
+    auto bail = [&](int code) { bls381_ctx_destroy(c); return code; };
+    if (hipStreamCreate(&c->stream) != hipSuccess) return bail(fail(BLS381_ERR_HIP, "hipStreamCreate failed"));
+    for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) return bail(fail(BLS381_ERR_HIP, "hipEventCreate failed"));
+    std::vector<uint32_t> consts, kp;
+    fill_constants(consts);
+    fill_kp(kp);
+    if (hipMalloc((void**)&c->d_consts, consts.size() * 4) != hipSuccess ||
+        hipMalloc((void**)&c->d_kp, kp.size() * 4) != hipSuccess ||
+        hipMemcpy(c->d_consts, consts.data(), consts.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_kp, kp.data(), kp.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(BLS381_ERR_HIP, "constant upload failed"));
+    for (const char* nm : ALL_PROGRAMS) {
+        rc = upload_program(c, nm);
+        if (rc) return bail(rc);
+    }
+    *out = c;
+    return 0;
+}
+extern "C" int bls381_ctx_create(bls381_ctx** out, int device_id) { return bls381_ctx_create_ex(out, device_id, 0, 0); }
+
+extern "C" void bls381_ctx_destroy(bls381_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (auto& kv : c->progs) { (void)hipFree(kv.second.d_hdrs); (void)hipFree(kv.second.d_descs); }
+    for (DevBuf* b : {&c->user_in, &c->user_in2, &c->user_in3, &c->user_out, &c->flags, &c->bufA, &c->bufB, &c->bufC,
+                      &c->bufTmp, &c->zflags})
+        b->release();
+    c->wit.release();
+    if (c->d_consts) (void)hipFree(c->d_consts);
+    if (c->d_kp) (void)hipFree(c->d_kp);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ------------------------------------------------------------------ launch helpers
+static inline int pad_elems(size_t n) { return (int)((n + 63) / 64 * 64); }
+static inline size_t soa_bytes(int slots, int npad) { return (size_t)slots * 48 * npad; }
+
+template <int K>
+static hipError_t launch_vm_k(bls381_ctx* c, const DevProgram& p, const uint4* gin, uint4* gout, uint4* gtmp, int n,
+                              int npad) {
+    constexpr int GPW = 4 * (64 / K);
+    VmArgs a;
+    a.hdrs = p.d_hdrs; a.descs = p.d_descs; a.nsteps = (int)p.host.hdrs.size(); a.lds_slots = p.host.n_lds_slots;
+    a.consts = c->d_consts; a.kp = c->d_kp; a.gin = gin; a.gout = gout; a.gtmp = gtmp; a.n = n; a.npad = npad;
+    size_t lds = (size_t)p.host.n_lds_slots * 48 * GPW + KP_ROWS * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)vm_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    int blocks = (n + GPW - 1) / GPW;
+    hipLaunchKernelGGL(vm_kernel<K>, dim3(blocks), dim3(VM_THREADS), lds, c->stream, a);
+    return hipGetLastError();
+}
+
+static int run_program(bls381_ctx* c, const char* which, const void* gin, void* gout, int n, int npad) {
+    auto it = c->progs.find(which);
+    if (it == c->progs.end()) return fail(BLS381_ERR_INVALID, std::string("no program ") + which);
+    const DevProgram& p = it->second;
+    HIPCHK(c->bufTmp.ensure(soa_bytes(std::max(1, p.host.n_tmp_slots), npad)));
+    hipError_t e;
+    switch (c->K) {
+        case 6: e = launch_vm_k<6>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)c->bufTmp.p, n, npad); break;
+        case 8: e = launch_vm_k<8>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)c->bufTmp.p, n, npad); break;
+        case 9: e = launch_vm_k<9>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)c->bufTmp.p, n, npad); break;
+        case 12: e = launch_vm_k<12>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)c->bufTmp.p, n, npad); break;
+        default: e = launch_vm_k<16>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)c->bufTmp.p, n, npad); break;
+    }
+    if (e != hipSuccess) return fail(BLS381_ERR_HIP, std::string("vm_kernel launch (") + which + "): " + hipGetErrorString(e));
+    return 0;
+}
+
+static int pack(bls381_ctx* c, const void* aos_dev, void* soa, int n, int npad, int fp_per_elem, int slot0) {
+    long total = (long)n * fp_per_elem;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, (const u32*)aos_dev,
+                       (uint4*)soa, n, npad, fp_per_elem, slot0);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int unpack(bls381_ctx* c, const void* soa, void* aos_dev, int n, int npad, int fp_per_elem, int slot0) {
+    long total = (long)n * fp_per_elem;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, (const uint4*)soa,
+                       (u32*)aos_dev, n, npad, fp_per_elem, slot0);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+enum { CHUNK = 1 << 16 };
+
+// final exponentiation of `n` Fq12 sitting in slots 0..11 of `fin` (SoA); result to slots 0..11 of `fout`.
+static int final_exp_soa(bls381_ctx* c, const void* fin, void* fout, int n, int npad, uint8_t* zero_dev,
+                         const char* part2 = "fe2") {
+    HIPCHK(c->bufC.ensure(soa_bytes(FE_CARRY, npad)));
+    int rc = run_program(c, "fe1", fin, c->bufC.p, n, npad);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fp_inverse_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, (uint4*)c->bufC.p, 0, n, npad,
+                       c->d_consts, zero_dev);
+    HIPCHK(hipGetLastError());
+    return run_program(c, part2, c->bufC.p, fout, n, npad);
+}
+
+// ------------------------------------------------------------------ device-pointer entry points
+static int miller_dev_locked(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags, size_t n,
+                             uint64_t* out, bool with_final_exp) {
+    for (size_t off = 0; off < n; off += CHUNK) {
+        int m = (int)std::min<size_t>(CHUNK, n - off);
+        int npad = pad_elems(m);
+        HIPCHK(c->bufA.ensure(soa_bytes(6, npad)));
+        HIPCHK(c->bufB.ensure(soa_bytes(12, npad)));
+        HIPCHK(hipEventRecord(c->ev[0], c->stream));
+        int rc = pack(c, g1 + off * 12, c->bufA.p, m, npad, 2, 0);
+        if (rc) return rc;
+        rc = pack(c, g2 + off * 24, c->bufA.p, m, npad, 4, 2);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(c->ev[1], c->stream));
+        rc = run_program(c, "miller", c->bufA.p, c->bufB.p, m, npad);
+        if (rc) return rc;
+        if (flags) {
+            hipLaunchKernelGGL(set_one_where_flag, dim3((m + 255) / 256), dim3(256), 0, c->stream, (uint4*)c->bufB.p,
+                               flags + off, c->d_consts, m, npad);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipEventRecord(c->ev[2], c->stream));
+        if (with_final_exp) {
+            rc = final_exp_soa(c, c->bufB.p, c->bufB.p, m, npad, nullptr);
+            if (rc) return rc;
+        }
+        HIPCHK(hipEventRecord(c->ev[3], c->stream));
+        rc = unpack(c, c->bufB.p, out + off * 72, m, npad, 12, 0);
+        if (rc) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n) {
+        (void)hipEventElapsedTime(&c->last_ms[0], c->ev[1], c->ev[2]);
+        (void)hipEventElapsedTime(&c->last_ms[1], c->ev[2], c->ev[3]);
+        (void)hipEventElapsedTime(&c->last_ms[2], c->ev[0], c->ev[3]);
+    }
+    return 0;
+}
+
+#define CTX_GUARD(c)                                                     \
+    if (!(c)) return fail(BLS381_ERR_INVALID, "ctx is NULL");            \
+    std::lock_guard<std::mutex> lock_((c)->mu);                          \
+    HIPCHK(hipSetDevice((c)->device));
+
+extern "C" int bls381_pairing_batch_dev(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags,
+                                        size_t n, uint64_t* out) {
+    CTX_GUARD(c);
+    if (n && (!g1 || !g2 || !out)) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    return miller_dev_locked(c, g1, g2, flags, n, out, true);
+}
+extern "C" int bls381_miller_loop_batch_dev(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags,
+                                            size_t n, uint64_t* out) {
+    CTX_GUARD(c);
+    if (n && (!g1 || !g2 || !out)) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    return miller_dev_locked(c, g1, g2, flags, n, out, false);
+}
+
+// generic "n x in_fp Fp in -> program -> n x out_fp Fp out" on device pointers (up to 3 input arrays)
+struct InArr { const void* p; int fp; };
+static int simple_dev_locked(bls381_ctx* c, const char* prog, std::vector<InArr> ins, size_t n, void* out, int out_fp,
+                             size_t chunk = CHUNK) {
+    int in_fp = 0;
+    for (auto& a : ins) in_fp += a.fp;
+    for (size_t off = 0; off < n; off += chunk) {
+        int m = (int)std::min<size_t>(chunk, n - off);
+        int npad = pad_elems(m);
+        HIPCHK(c->bufA.ensure(soa_bytes(in_fp, npad)));
+        HIPCHK(c->bufB.ensure(soa_bytes(out_fp, npad)));
+        int slot = 0;
+        for (auto& a : ins) {
+            int rc = pack(c, (const u32*)a.p + off * a.fp * 12, c->bufA.p, m, npad, a.fp, slot);
+            if (rc) return rc;
+            slot += a.fp;
+        }
+        int rc = run_program(c, prog, c->bufA.p, c->bufB.p, m, npad);
+        if (rc) return rc;
+        rc = unpack(c, c->bufB.p, (u32*)out + off * out_fp * 12, m, npad, out_fp, 0);
+        if (rc) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int final_exp_dev_locked(bls381_ctx* c, const uint64_t* in, size_t n, uint64_t* out, uint8_t* zero_dev,
+                                const char* part2) {
+    for (size_t off = 0; off < n; off += CHUNK) {
+        int m = (int)std::min<size_t>(CHUNK, n - off);
+        int npad = pad_elems(m);
+        HIPCHK(c->bufA.ensure(soa_bytes(12, npad)));
+        HIPCHK(c->bufB.ensure(soa_bytes(12, npad)));
+        HIPCHK(hipEventRecord(c->ev[0], c->stream));
+        int rc = pack(c, in + off * 72, c->bufA.p, m, npad, 12, 0);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(c->ev[2], c->stream));
+        rc = final_exp_soa(c, c->bufA.p, c->bufB.p, m, npad, zero_dev ? zero_dev + off : nullptr, part2);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(c->ev[3], c->stream));
+        rc = unpack(c, c->bufB.p, out + off * 72, m, npad, 12, 0);
+        if (rc) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n) {
+        c->last_ms[0] = 0;
+        (void)hipEventElapsedTime(&c->last_ms[1], c->ev[2], c->ev[3]);
+        (void)hipEventElapsedTime(&c->last_ms[2], c->ev[0], c->ev[3]);
+    }
+    return 0;
+}
+extern "C" int bls381_final_exp_batch_dev(bls381_ctx* c, const uint64_t* in, size_t n, uint64_t* out, uint8_t* zero_dev) {
+    CTX_GUARD(c);
+    if (n && (!in || !out)) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    return final_exp_dev_locked(c, in, n, out, zero_dev, "fe2");
+}
+
+// ------------------------------------------------------------------ host-pointer entry points
+static int h2d(bls381_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+    HIPCHK(b.ensure(std::max<size_t>(bytes, 16)));
+    if (bytes) HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+static int pairs_host(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags, size_t n,
+                      uint64_t* out, bool fe) {
+    if (n && (!g1 || !g2 || !out)) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    if (n == 0) return 0;
+    int rc;
+    if ((rc = h2d(c, c->user_in, g1, n * 96))) return rc;
+    if ((rc = h2d(c, c->user_in2, g2, n * 192))) return rc;
+    std::vector<uint8_t> f;
+    const uint8_t* fdev = nullptr;
+    if (flags) {
+        if ((rc = h2d(c, c->flags, flags, n))) return rc;
+        fdev = (const uint8_t*)c->flags.p;
+    }
+    HIPCHK(c->user_out.ensure(n * 576));
+    rc = miller_dev_locked(c, (const uint64_t*)c->user_in.p, (const uint64_t*)c->user_in2.p, fdev, n,
+                           (uint64_t*)c->user_out.p, fe);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out, c->user_out.p, n * 576, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int bls381_miller_loop_batch(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags,
+                                        size_t n, uint64_t* out) {
+    CTX_GUARD(c);
+    return pairs_host(c, g1, g2, flags, n, out, false);
+}
+extern "C" int bls381_pairing_batch(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags, size_t n,
+                                    uint64_t* out) {
+    CTX_GUARD(c);
+    return pairs_host(c, g1, g2, flags, n, out, true);
+}
+
+static int fe_host(bls381_ctx* c, const uint64_t* in, size_t n, uint64_t* out, uint8_t* zero, const char* part2) {
+    if (n && (!in || !out)) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    if (n == 0) return 0;
+    int rc;
+    if ((rc = h2d(c, c->user_in, in, n * 576))) return rc;
+    HIPCHK(c->user_out.ensure(n * 576));
+    HIPCHK(c->zflags.ensure(n));
+    rc = final_exp_dev_locked(c, (const uint64_t*)c->user_in.p, n, (uint64_t*)c->user_out.p, (uint8_t*)c->zflags.p, part2);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out, c->user_out.p, n * 576, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> z(n);
+    HIPCHK(hipMemcpy(z.data(), c->zflags.p, n, hipMemcpyDeviceToHost));
+    if (zero) std::memcpy(zero, z.data(), n);
+    for (size_t i = 0; i < n; i++)
+        if (z[i]) return fail(BLS381_ERR_ZERO, "final exponentiation of zero (item " + std::to_string(i) + ")");
+    return 0;
+}
+extern "C" int bls381_final_exp_batch(bls381_ctx* c, const uint64_t* in, size_t n, uint64_t* out, uint8_t* zero) {
+    CTX_GUARD(c);
+    return fe_host(c, in, n, out, zero, "fe2");
+}
+extern "C" int bls381_easy_part_batch(bls381_ctx* c, const uint64_t* in, size_t n, uint64_t* out, uint8_t* zero) {
+    CTX_GUARD(c);
+    return fe_host(c, in, n, out, zero, "easy2");
+}
+
+static int simple_host(bls381_ctx* c, const char* prog, std::vector<InArr> ins, size_t n, void* out, int out_fp,
+                       size_t chunk = CHUNK) {
+    if (n == 0) return 0;
+    for (auto& a : ins) if (!a.p) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    if (!out) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    DevBuf* bufs[3] = {&c->user_in, &c->user_in2, &c->user_in3};
+    std::vector<InArr> dins;
+    for (size_t i = 0; i < ins.size(); i++) {
+        int rc = h2d(c, *bufs[i], ins[i].p, n * ins[i].fp * 48);
+        if (rc) return rc;
+        dins.push_back(InArr{bufs[i]->p, ins[i].fp});
+    }
+    HIPCHK(c->user_out.ensure(n * out_fp * 48));
+    int rc = simple_dev_locked(c, prog, dins, n, c->user_out.p, out_fp, chunk);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out, c->user_out.p, n * out_fp * 48, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int bls381_hard_part_batch(bls381_ctx* c, const uint64_t* in, size_t n, uint64_t* out) {
+    CTX_GUARD(c);
+    return simple_host(c, "hardgen", {{in, 12}}, n, out, 12);
+}
+extern "C" int bls381_frobenius_batch(bls381_ctx* c, const uint64_t* in, int power, size_t n, uint64_t* out) {
+    CTX_GUARD(c);
+    if (power != 1 && power != 2) return fail(BLS381_ERR_INVALID, "power must be 1 or 2");
+    return simple_host(c, power == 1 ? "frob1" : "frob2", {{in, 12}}, n, out, 12);
+}
+extern "C" int bls381_fq12_mul_batch(bls381_ctx* c, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+    CTX_GUARD(c);
+    return simple_host(c, "fq12mul", {{a, 12}, {b, 12}}, n, out, 12);
+}
+extern "C" int bls381_g2_prepare_batch(bls381_ctx* c, const uint64_t* g2, size_t n, uint64_t* out) {
+    CTX_GUARD(c);
+    return simple_host(c, "g2prep", {{g2, 4}}, n, out, 68 * 6, 4096);
+}
+extern "C" int bls381_ell_batch(bls381_ctx* c, const uint64_t* f, const uint64_t* coeffs, const uint64_t* g1, size_t n,
+                                uint64_t* out) {
+    CTX_GUARD(c);
+    return simple_host(c, "ell", {{f, 12}, {coeffs, 6}, {g1, 2}}, n, out, 12);
+}
+
+// product of m Fq12 held in slots 0..11 of `src` (SoA, stride npad_src); result lands in c->bufB slots 0..11, element 0
+static int product_tree(bls381_ctx* c, const void* src, int m, int npad_src) {
+    const void* cur = src;
+    int cur_pad = npad_src;
+    bool first = true;  // a single value still goes through one multiplication by one, into bufB
+    while (m > 1 || first) {
+        first = false;
+        int h = (m + 1) / 2;
+        int npad = pad_elems(h);
+        // stage operands in bufA (24 slots), product to bufB (12 slots)
+        HIPCHK(c->bufA.ensure(soa_bytes(24, npad)));
+        hipLaunchKernelGGL(tree_pack_kernel, dim3((h * 12 + 255) / 256), dim3(256), 0, c->stream, (const uint4*)cur,
+                           (uint4*)c->bufA.p, c->d_consts, m, h, cur_pad, npad);
+        HIPCHK(hipGetLastError());
+        HIPCHK(c->bufB.ensure(soa_bytes(12, npad)));
+        int rc = run_program(c, "fq12mul", c->bufA.p, c->bufB.p, h, npad);
+        if (rc) return rc;
+        cur = c->bufB.p; cur_pad = npad; m = h;
+    }
+    return 0;
+}
+
+static int multi_host(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags, size_t n,
+                      uint64_t out[72], int* is_one, bool fe) {
+    if (!out) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    if (n > (size_t)CHUNK * 16) return fail(BLS381_ERR_INVALID, "n_pairs too large");
+    if (n && (!g1 || !g2)) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    int rc;
+    int m = (int)n;
+    HIPCHK(c->bufC.ensure(soa_bytes(FE_CARRY, 64)));
+    if (m == 0) {
+        // empty product: one (the reference's fold over zero chunks), still conjugated / exponentiated
+        uint64_t one[72] = {0};
+        std::memcpy(one, BLS381_ONE_MONT, 48);
+        std::memcpy(out, one, sizeof one);
+        if (is_one) *is_one = 1;
+        return 0;
+    }
+    int npad = pad_elems(m);
+    if ((rc = h2d(c, c->user_in, g1, n * 96))) return rc;
+    if ((rc = h2d(c, c->user_in2, g2, n * 192))) return rc;
+    const uint8_t* fdev = nullptr;
+    if (flags) {
+        if ((rc = h2d(c, c->flags, flags, n))) return rc;
+        fdev = (const uint8_t*)c->flags.p;
+    }
+    // per-pair Miller values into bufC-sized SoA held in user_out (12 slots)
+    HIPCHK(c->bufA.ensure(soa_bytes(24, npad)));
+    HIPCHK(c->user_out.ensure(soa_bytes(12, npad)));
+    if ((rc = pack(c, c->user_in.p, c->bufA.p, m, npad, 2, 0))) return rc;
+    if ((rc = pack(c, c->user_in2.p, c->bufA.p, m, npad, 4, 2))) return rc;
+    if ((rc = run_program(c, "miller", c->bufA.p, c->user_out.p, m, npad))) return rc;
+    if (fdev) {
+        hipLaunchKernelGGL(set_one_where_flag, dim3((m + 255) / 256), dim3(256), 0, c->stream, (uint4*)c->user_out.p,
+                           fdev, c->d_consts, m, npad);
+        HIPCHK(hipGetLastError());
+    }
+    if ((rc = product_tree(c, c->user_out.p, m, npad))) return rc;
+    if (fe) {
+        if ((rc = final_exp_soa(c, c->bufB.p, c->bufB.p, 1, 64, nullptr))) return rc;
+    }
+    HIPCHK(c->user_in3.ensure(576));
+    if ((rc = unpack(c, c->bufB.p, c->user_in3.p, 1, 64, 12, 0))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->user_in3.p, 576, hipMemcpyDeviceToHost));
+    if (is_one) {
+        uint64_t one[72] = {0};
+        std::memcpy(one, BLS381_ONE_MONT, 48);
+        *is_one = std::memcmp(out, one, sizeof one) == 0;
+    }
+    return 0;
+}
+extern "C" int bls381_multi_miller_loop(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags,
+                                        size_t n, uint64_t out[72]) {
+    CTX_GUARD(c);
+    return multi_host(c, g1, g2, flags, n, out, nullptr, false);
+}
+extern "C" int bls381_multi_pairing(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags, size_t n,
+                                    uint64_t out[72], int* is_one) {
+    CTX_GUARD(c);
+    return multi_host(c, g1, g2, flags, n, out, is_one, true);
+}
+extern "C" int bls381_finish_multi_pairing(bls381_ctx* c, const uint64_t* partials, size_t n, uint64_t out[72],
+                                           int* is_one) {
+    CTX_GUARD(c);
+    if (!partials || !out || n == 0) return fail(BLS381_ERR_INVALID, "NULL buffer or no partials");
+    if (n > CHUNK) return fail(BLS381_ERR_INVALID, "too many partials");
+    int rc;
+    int m = (int)n, npad = pad_elems(m);
+    if ((rc = h2d(c, c->user_in, partials, n * 576))) return rc;
+    HIPCHK(c->user_out.ensure(soa_bytes(12, npad)));
+    HIPCHK(c->bufA.ensure(soa_bytes(24, npad)));
+    if ((rc = pack(c, c->user_in.p, c->user_out.p, m, npad, 12, 0))) return rc;
+    if ((rc = product_tree(c, c->user_out.p, m, npad))) return rc;
+    if ((rc = final_exp_soa(c, c->bufB.p, c->bufB.p, 1, 64, nullptr))) return rc;
+    HIPCHK(c->user_in3.ensure(576));
+    if ((rc = unpack(c, c->bufB.p, c->user_in3.p, 1, 64, 12, 0))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->user_in3.p, 576, hipMemcpyDeviceToHost));
+    if (is_one) {
+        uint64_t one[72] = {0};
+        std::memcpy(one, BLS381_ONE_MONT, 48);
+        *is_one = std::memcmp(out, one, sizeof one) == 0;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ Fq12 inverse on witness limbs
+extern "C" int bls381_fq12_inverse_limbs_batch(bls381_ctx* c, const uint32_t* x, size_t n, uint32_t* inv, uint8_t* err) {
+    CTX_GUARD(c);
+    if (n == 0) return 0;
+    if (!x || !inv) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    // range check on the host: from_biguint_to_fq (src/utils/helpers.rs:154-157) rejects values >= p
+    std::vector<uint8_t> e(n, 0);
+    bool bad = false;
+    for (size_t i = 0; i < n; i++)
+        for (int k = 0; k < 12; k++) {
+            const uint32_t* v = x + (i * 12 + k) * 12;
+            int cmp = 0;
+            for (int l = 11; l >= 0 && cmp == 0; l--) cmp = v[l] < BLS381_P[l] ? -1 : (v[l] > BLS381_P[l] ? 1 : 0);
+            if (cmp >= 0) { e[i] = 1; bad = true; }
+        }
+    int rc;
+    for (size_t off = 0; off < n; off += CHUNK) {
+        int m = (int)std::min<size_t>(CHUNK, n - off);
+        int npad = pad_elems(m);
+        if ((rc = h2d(c, c->user_in, x + off * 144, (size_t)m * 576))) return rc;
+        HIPCHK(c->bufA.ensure(soa_bytes(12, npad)));
+        HIPCHK(c->bufB.ensure(soa_bytes(12, npad)));
+        HIPCHK(c->bufC.ensure(soa_bytes(FE_CARRY, npad)));
+        HIPCHK(c->zflags.ensure(m));
+        HIPCHK(c->user_out.ensure((size_t)m * 576));
+        if ((rc = pack(c, c->user_in.p, c->bufA.p, m, npad, 12, 0))) return rc;
+        if ((rc = run_program(c, "inv1", c->bufA.p, c->bufC.p, m, npad))) return rc;
+        hipLaunchKernelGGL(fp_inverse_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, (uint4*)c->bufC.p, 0, m, npad,
+                           c->d_consts, (uint8_t*)c->zflags.p);
+        HIPCHK(hipGetLastError());
+        if ((rc = run_program(c, "inv2", c->bufC.p, c->bufB.p, m, npad))) return rc;
+        if ((rc = unpack(c, c->bufB.p, c->user_out.p, m, npad, 12, 0))) return rc;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpy(inv + off * 144, c->user_out.p, (size_t)m * 576, hipMemcpyDeviceToHost));
+        std::vector<uint8_t> z(m);
+        HIPCHK(hipMemcpy(z.data(), c->zflags.p, m, hipMemcpyDeviceToHost));
+        for (int i = 0; i < m; i++) if (z[i] && !e[off + i]) { e[off + i] = 2; bad = true; }
+    }
+    if (err) std::memcpy(err, e.data(), n);
+    if (bad) return fail(BLS381_ERR_ZERO, "an input is zero or has a coefficient >= p");
+    return 0;
+}
+
+// ------------------------------------------------------------------ witness trace
+extern "C" size_t bls381_pairing_witness_rows(void) { return witness_program().n_rows; }
+extern "C" int bls381_pairing_witness_kinds(uint8_t* kinds, size_t capacity) {
+    const WitnessProgram& w = witness_program();
+    if (!kinds || capacity < w.n_rows) return fail(BLS381_ERR_INVALID, "kinds buffer too small");
+    std::memcpy(kinds, w.kinds.data(), w.n_rows);
+    return 0;
+}
+extern "C" int bls381_pairing_witness_batch(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t n,
+                                            uint32_t* trace) {
+    CTX_GUARD(c);
+    if (n == 0) return 0;
+    if (!g1 || !g2 || !trace) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    std::string err;
+    int rc = c->wit.run(c->stream, (const uint4*)c->d_consts, g1, g2, n, trace, err);
+    if (rc) return fail(rc, err);
+    return 0;
+}
+
+// ------------------------------------------------------------------ introspection
+extern "C" int bls381_debug_program(const char* which, int K, int lds_slots, uint32_t* hdrs, uint32_t* descs,
+                                    size_t capacity_steps, uint32_t info[8]) {
+    if (!which || !info) return fail(BLS381_ERR_INVALID, "NULL argument");
+    if (K == 0) K = 8;
+    if (!valid_k(K)) return fail(BLS381_ERR_INVALID, "bad K");
+    if (lds_slots == 0) lds_slots = default_slots(K);
+    Program p;
+    try {
+        p = schedule(build_named(which), K, lds_slots, which);
+    } catch (std::exception& e) {
+        return fail(BLS381_ERR_INVALID, e.what());
+    }
+    info[0] = K; info[1] = (uint32_t)p.hdrs.size(); info[2] = p.n_lds_slots; info[3] = p.n_tmp_slots;
+    info[4] = p.n_in; info[5] = p.n_out; info[6] = p.n_fmul; info[7] = p.n_lin;
+    if (hdrs && descs) {
+        if (capacity_steps < p.hdrs.size()) return fail(BLS381_ERR_INVALID, "capacity too small");
+        std::memcpy(hdrs, p.hdrs.data(), p.hdrs.size() * sizeof(StepHdr));
+        std::memcpy(descs, p.descs.data(), p.descs.size() * sizeof(OpDesc));
+    }
+    return 0;
+}
+extern "C" int bls381_debug_constants(uint32_t* out, size_t capacity_fp) {
+    if (!out || capacity_fp < C_COUNT) return fail(BLS381_ERR_INVALID, "buffer too small");
+    std::vector<uint32_t> c;
+    fill_constants(c);
+    std::memcpy(out, c.data(), c.size() * 4);
+    return 0;
+}
+extern "C" int bls381_last_timing(bls381_ctx* c, float ms[3]) {
+    if (!c || !ms) return fail(BLS381_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lock_(c->mu);
+    ms[0] = c->last_ms[0]; ms[1] = c->last_ms[1]; ms[2] = c->last_ms[2];
+    return 0;
+}
+
+// sustained v_mad_u64_u32 rate: 8 independent accumulators per lane, 8 waves per SIMD
+__global__ void mac_rate_kernel(u32* out, u32 seed, int iters) {
+    u32 a = seed + threadIdx.x, b = seed * 3 + blockIdx.x;
+    u64 acc[8];
+    for (int i = 0; i < 8; i++) acc[i] = i + seed;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[i] = (u64)a * b + acc[i];
+        a += (u32)acc[0];
+    }
+    u64 s = 0;
+    for (int i = 0; i < 8; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (u32)s ^ (u32)(s >> 32);
+}
+extern "C" int bls381_calibrate_mac_rate(bls381_ctx* c, double* mac_per_s) {
+    CTX_GUARD(c);
+    if (!mac_per_s) return fail(BLS381_ERR_INVALID, "NULL argument");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, c->device));
+    int blocks = prop.multiProcessorCount * 8, iters = 8192;
+    HIPCHK(c->user_out.ensure((size_t)blocks * 256 * 4));
+    double best = 0;
+    for (int rep = 0; rep < 4; rep++) {
+        HIPCHK(hipEventRecord(c->ev[0], c->stream));
+        hipLaunchKernelGGL(mac_rate_kernel, dim3(blocks), dim3(256), 0, c->stream, (u32*)c->user_out.p, 17u + rep, iters);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->ev[1], c->stream));
+        HIPCHK(hipEventSynchronize(c->ev[1]));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        double rate = (double)blocks * 256 * iters * 8 / (ms * 1e-3);
+        if (rep > 0) best = std::max(best, rate);
+    }
+    *mac_per_s = best;
+    return 0;
+}

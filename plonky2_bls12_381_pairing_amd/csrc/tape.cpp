@@ -1,0 +1,353 @@
+// Dag bookkeeping, the LIN-inlining pass, and the K-wide list scheduler with LDS slot
+// assignment (furthest-next-use eviction to the global spill array).
+#include "tape.h"
+
+#include <algorithm>
+#include <cassert>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <set>
+#include <stdexcept>
+
+namespace bls381 {
+
+int Dag::load_in(int slot) {
+    Node n; n.kind = NK_LOADIN; n.idx = slot;
+    nodes.push_back(n);
+    return (int)nodes.size() - 1;
+}
+int Dag::load_const(int cid) {
+    Node n; n.kind = NK_LOADC; n.idx = cid;
+    nodes.push_back(n);
+    return (int)nodes.size() - 1;
+}
+int Dag::fmul(int a, int b) {
+    assert(a >= 0 && b >= 0);
+    Node n; n.kind = NK_FMUL; n.a = a; n.b = b;
+    nodes.push_back(n);
+    return (int)nodes.size() - 1;
+}
+int Dag::lin(std::vector<Term> terms) {
+    assert(!terms.empty());
+    Node n; n.kind = NK_LIN; n.terms = std::move(terms);
+    nodes.push_back(n);
+    return (int)nodes.size() - 1;
+}
+void Dag::store_out(int node, int slot) {
+    assert(node >= 0);
+    Node n; n.kind = NK_STOREOUT; n.a = node; n.idx = slot;
+    nodes.push_back(n);
+}
+
+static void for_each_src(const Node& n, const std::function<void(int)>& f) {
+    switch (n.kind) {
+        case NK_FMUL: f(n.a); f(n.b); break;
+        case NK_LIN: for (auto& t : n.terms) f(t.node); break;
+        case NK_STOREOUT: f(n.a); break;
+        default: break;
+    }
+}
+
+void Dag::optimise() {
+    const int n = (int)nodes.size();
+    std::vector<int> uses(n, 0);
+    for (auto& nd : nodes) for_each_src(nd, [&](int s) { uses[s]++; });
+    // inline single-use LINs into LIN consumers
+    for (int i = 0; i < n; i++) {
+        Node& nd = nodes[i];
+        if (nd.kind != NK_LIN) continue;
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            for (size_t k = 0; k < nd.terms.size(); k++) {
+                Term t = nd.terms[k];
+                const Node& in = nodes[t.node];
+                if (in.kind != NK_LIN || uses[t.node] != 1) continue;
+                if (nd.terms.size() - 1 + in.terms.size() > (size_t)LIN_MAX_TERMS) continue;
+                std::vector<Term> nt;
+                for (size_t j = 0; j < nd.terms.size(); j++) {
+                    if (j != k) { nt.push_back(nd.terms[j]); continue; }
+                    for (auto& it : in.terms) nt.push_back(Term{it.node, it.neg != t.neg});
+                }
+                uses[t.node] = 0;
+                nd.terms = nt;
+                changed = true;
+                break;
+            }
+        }
+    }
+    // dead-code elimination
+    std::vector<char> live(n, 0);
+    for (int i = n - 1; i >= 0; i--) {
+        if (nodes[i].kind == NK_STOREOUT) live[i] = 1;
+        if (live[i]) for_each_src(nodes[i], [&](int s) { live[s] = 1; });
+    }
+    std::vector<int> remap(n, -1);
+    std::vector<Node> out;
+    for (int i = 0; i < n; i++) {
+        if (!live[i]) continue;
+        Node nd = nodes[i];
+        if (nd.kind == NK_FMUL) { nd.a = remap[nd.a]; nd.b = remap[nd.b]; }
+        else if (nd.kind == NK_STOREOUT) { nd.a = remap[nd.a]; }
+        else if (nd.kind == NK_LIN) for (auto& t : nd.terms) t.node = remap[t.node];
+        remap[i] = (int)out.size();
+        out.push_back(nd);
+    }
+    nodes.swap(out);
+}
+
+// ------------------------------------------------------------------------------- scheduler
+namespace {
+
+enum OpClass { OC_FMUL = 0, OC_LIN = 1, OC_COPY = 2 };
+inline OpClass class_of(NodeKind k) {
+    if (k == NK_FMUL) return OC_FMUL;
+    if (k == NK_LIN) return OC_LIN;
+    return OC_COPY;
+}
+
+struct RawStep {
+    OpClass cls;
+    std::vector<int> ops;  // node ids
+};
+
+struct CopyOp {
+    CopyKind kind;
+    int dst, src;
+};
+
+}  // namespace
+
+Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) {
+    const std::vector<Node>& N = dag.nodes;
+    const int n = (int)N.size();
+    Program P;
+    P.name = name; P.K = K; P.n_in = dag.n_in; P.n_out = dag.n_out;
+
+    std::vector<std::vector<int>> succ(n);
+    std::vector<int> npred(n, 0);
+    for (int i = 0; i < n; i++) {
+        std::set<int> srcs;
+        for_each_src(N[i], [&](int s) { srcs.insert(s); });
+        for (int s : srcs) { succ[s].push_back(i); npred[i]++; }
+    }
+    // priority = longest weighted path to a sink
+    std::vector<int> prio(n, 0);
+    for (int i = n - 1; i >= 0; i--) {
+        int w = N[i].kind == NK_FMUL ? 7 : (N[i].kind == NK_LIN ? 2 : 1);
+        int best = 0;
+        for (int s : succ[i]) best = std::max(best, prio[s]);
+        prio[i] = best + w;
+    }
+
+    // ---- pass 1: list scheduling into K-wide single-class steps
+    const int WINDOW = 600;
+    std::vector<char> done(n, 0);
+    std::vector<int> ready;  // nodes whose predecessors all sit in closed steps
+    for (int i = 0; i < n; i++) if (npred[i] == 0) ready.push_back(i);
+    std::vector<RawStep> raw;
+    int lo = 0, n_done = 0;
+    while (n_done < n) {
+        while (lo < n && done[lo]) lo++;
+        std::vector<int> cand[3];
+        for (int r : ready) if (r < lo + WINDOW) cand[class_of(N[r].kind)].push_back(r);
+        int cls;
+        if ((int)cand[OC_FMUL].size() >= K) cls = OC_FMUL;
+        else if (!cand[OC_LIN].empty()) cls = OC_LIN;
+        else if (!cand[OC_COPY].empty()) cls = OC_COPY;
+        else if (!cand[OC_FMUL].empty()) cls = OC_FMUL;
+        else throw std::runtime_error("scheduler: no candidate");
+        auto& c = cand[cls];
+        std::sort(c.begin(), c.end(), [&](int a, int b) {
+            if (prio[a] != prio[b]) return prio[a] > prio[b];
+            return a < b;
+        });
+        if ((int)c.size() > K) c.resize(K);
+        RawStep st; st.cls = (OpClass)cls; st.ops = c;
+        std::set<int> chosen(c.begin(), c.end());
+        std::vector<int> nr;
+        for (int r : ready) if (!chosen.count(r)) nr.push_back(r);
+        for (int x : c) {
+            done[x] = 1; n_done++;
+            for (int s : succ[x]) if (--npred[s] == 0) nr.push_back(s);
+        }
+        ready.swap(nr);
+        raw.push_back(st);
+    }
+
+    // ---- pass 2: LDS slot assignment with spilling
+    const int S = (int)raw.size();
+    std::vector<std::vector<int>> use_steps(n);  // steps in which a node's value is read
+    for (int s = 0; s < S; s++)
+        for (int op : raw[s].ops) {
+            std::set<int> srcs;
+            for_each_src(N[op], [&](int x) { srcs.insert(x); });
+            for (int x : srcs) use_steps[x].push_back(s);
+        }
+    std::vector<size_t> use_ptr(n, 0);
+    auto next_use = [&](int node, int after_step) -> int {  // first use step > after_step, or INT_MAX
+        auto& u = use_steps[node];
+        size_t p = use_ptr[node];
+        while (p < u.size() && u[p] <= after_step) p++;
+        return p < u.size() ? u[p] : 0x7fffffff;
+    };
+
+    std::vector<int> lds_of(n, -1), tmp_of(n, -1);
+    std::vector<int> owner(lds_slots, -1);
+    std::vector<int> free_lds;
+    for (int i = lds_slots - 1; i >= 0; i--) free_lds.push_back(i);
+    std::vector<int> free_tmp;
+    int n_tmp = 0;
+
+    auto emit_copy_steps = [&](std::vector<CopyOp>& ops) {
+        for (size_t base = 0; base < ops.size(); base += K) {
+            StepHdr h{ST_COPY, 0};
+            P.hdrs.push_back(h);
+            for (int r = 0; r < K; r++) {
+                OpDesc d; std::memset(&d, 0, sizeof d);
+                if (base + r < ops.size()) {
+                    const CopyOp& c = ops[base + r];
+                    d.hdr = 1u | ((uint32_t)c.kind << 8);
+                    d.w[0] = (uint16_t)c.dst; d.w[1] = (uint16_t)c.src;
+                    P.n_copy++;
+                }
+                P.descs.push_back(d);
+            }
+            P.n_copy_steps++;
+        }
+        ops.clear();
+    };
+
+    for (int s = 0; s < S; s++) {
+        const RawStep& st = raw[s];
+        std::set<int> srcs;
+        for (int op : st.ops) for_each_src(N[op], [&](int x) { srcs.insert(x); });
+        std::vector<CopyOp> spills_a, spills_b, fills;
+        std::vector<CopyOp>* spills = &spills_a;
+        std::set<int> pinned(srcs.begin(), srcs.end());  // may not be evicted while forming this step
+
+        auto take_slot = [&]() -> int {
+            if (!free_lds.empty()) { int x = free_lds.back(); free_lds.pop_back(); return x; }
+            // evict the resident value with the furthest next use
+            int victim = -1, far = -1;
+            for (int sl = 0; sl < lds_slots; sl++) {
+                int o = owner[sl];
+                if (o < 0 || pinned.count(o)) continue;
+                int nu = next_use(o, s - 1);
+                if (nu > far) { far = nu; victim = sl; }
+            }
+            if (victim < 0) throw std::runtime_error("scheduler: LDS slots exhausted (" + name + ")");
+            int o = owner[victim];
+            bool clean = (N[o].kind == NK_LOADIN || N[o].kind == NK_LOADC || tmp_of[o] >= 0);
+            if (!clean && far != 0x7fffffff) {
+                int t;
+                if (!free_tmp.empty()) { t = free_tmp.back(); free_tmp.pop_back(); }
+                else t = n_tmp++;
+                tmp_of[o] = t;
+                spills->push_back(CopyOp{CK_SPILL, t, victim});
+            }
+            lds_of[o] = -1; owner[victim] = -1;
+            return victim;
+        };
+
+        // 1. bring non-resident sources back
+        for (int x : srcs) {
+            if (lds_of[x] >= 0) continue;
+            int sl = take_slot();
+            lds_of[x] = sl; owner[sl] = x;
+            if (N[x].kind == NK_LOADIN) fills.push_back(CopyOp{CK_IN, sl, N[x].idx});
+            else if (N[x].kind == NK_LOADC) fills.push_back(CopyOp{CK_CONST, sl, N[x].idx});
+            else { assert(tmp_of[x] >= 0); fills.push_back(CopyOp{CK_FILL, sl, tmp_of[x]}); }
+        }
+        // record operand slots now (before any source slot is recycled for a destination)
+        std::map<int, int> src_slot;
+        for (int x : srcs) src_slot[x] = lds_of[x];
+        // 2. release sources that die here
+        for (int x : srcs) {
+            if (next_use(x, s) == 0x7fffffff) {
+                int sl = lds_of[x];
+                owner[sl] = -1; lds_of[x] = -1; free_lds.push_back(sl);
+                if (tmp_of[x] >= 0) { free_tmp.push_back(tmp_of[x]); tmp_of[x] = -1; }
+            }
+        }
+        // 3. destinations.  Spills made from here on may reuse a spill-array slot released in (2),
+        //    which a fill of this very step still has to read: they run after the fills.
+        spills = &spills_b;
+        std::map<int, int> dst_slot;
+        for (int op : st.ops) {
+            if (N[op].kind == NK_STOREOUT) continue;
+            int sl = take_slot();
+            lds_of[op] = sl; owner[sl] = op; dst_slot[op] = sl;
+            pinned.insert(op);
+        }
+        // a spill reads LDS before this step's fills and results overwrite it
+        emit_copy_steps(spills_a);
+        emit_copy_steps(fills);
+        emit_copy_steps(spills_b);
+        // 4. the step itself
+        StepHdr h; h.max_terms = 0;
+        h.type = st.cls == OC_FMUL ? ST_FMUL : (st.cls == OC_LIN ? ST_LIN : ST_COPY);
+        for (int r = 0; r < K; r++) {
+            OpDesc d; std::memset(&d, 0, sizeof d);
+            if (r < (int)st.ops.size()) {
+                int op = st.ops[r];
+                const Node& nd = N[op];
+                d.hdr = 1u;
+                switch (nd.kind) {
+                    case NK_FMUL:
+                        d.w[0] = (uint16_t)dst_slot[op]; d.w[1] = (uint16_t)src_slot[nd.a]; d.w[2] = (uint16_t)src_slot[nd.b];
+                        P.n_fmul++;
+                        break;
+                    case NK_LIN: {
+                        int nt = (int)nd.terms.size();
+                        assert(nt <= LIN_MAX_TERMS);
+                        d.hdr |= (uint32_t)nt << 8;
+                        d.w[0] = (uint16_t)dst_slot[op];
+                        int nneg = 0;
+                        for (int t = 0; t < nt; t++) {
+                            d.w[1 + t] = (uint16_t)(src_slot[nd.terms[t].node] | (nd.terms[t].neg ? 0x8000 : 0));
+                            nneg += nd.terms[t].neg ? 1 : 0;
+                        }
+                        d.hdr |= (uint32_t)nneg << 16;  // bias multiple: acc starts at nneg * p
+                        h.max_terms = std::max<uint32_t>(h.max_terms, nt);
+                        P.n_lin++; P.n_lin_terms += nt;
+                        break;
+                    }
+                    case NK_LOADIN:
+                        d.hdr |= (uint32_t)CK_IN << 8; d.w[0] = (uint16_t)dst_slot[op]; d.w[1] = (uint16_t)nd.idx; P.n_copy++;
+                        break;
+                    case NK_LOADC:
+                        d.hdr |= (uint32_t)CK_CONST << 8; d.w[0] = (uint16_t)dst_slot[op]; d.w[1] = (uint16_t)nd.idx; P.n_copy++;
+                        break;
+                    case NK_STOREOUT:
+                        d.hdr |= (uint32_t)CK_OUT << 8; d.w[0] = (uint16_t)nd.idx; d.w[1] = (uint16_t)src_slot[nd.a]; P.n_copy++;
+                        break;
+                }
+            }
+            P.descs.push_back(d);
+        }
+        if (st.cls == OC_LIN) {
+            // acc <= max_terms * p, so r rounds of conditional subtraction (2^(r-1) p ... p) with
+            // 2^r > max_terms leave a canonical value
+            uint32_t r = 0;
+            while ((1u << r) <= h.max_terms) r++;
+            h.max_terms |= r << 8;
+        }
+        P.hdrs.push_back(h);
+        if (st.cls == OC_FMUL) P.n_fmul_steps++;
+        else if (st.cls == OC_LIN) P.n_lin_steps++;
+        else P.n_copy_steps++;
+        // values produced but never read (cannot happen after DCE) would leak a slot; guard anyway
+        for (int op : st.ops)
+            if (N[op].kind != NK_STOREOUT && use_steps[op].empty()) {
+                int sl = lds_of[op]; owner[sl] = -1; lds_of[op] = -1; free_lds.push_back(sl);
+            }
+    }
+    P.n_lds_slots = lds_slots;
+    P.n_tmp_slots = n_tmp;
+    return P;
+}
+
+}  // namespace bls381

@@ -1,0 +1,95 @@
+// Host-side program construction for the lane-group interpreter:
+//   Dag        - expression graph over Fp values (FMUL / LIN / loads / stores)
+//   tower      - symbolic Fq2/Fq6/Fq12 arithmetic and the pairing algorithms on top of Dag
+//   schedule() - list-schedules a Dag into K-wide steps and assigns LDS slots
+// The numeric work happens on the GPU; nothing here touches field values.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "vm_format.h"
+
+namespace bls381 {
+
+enum NodeKind : uint8_t { NK_FMUL, NK_LIN, NK_LOADIN, NK_LOADC, NK_STOREOUT };
+
+struct Term {
+    int node;
+    bool neg;
+};
+
+struct Node {
+    NodeKind kind;
+    int a = -1, b = -1;       // FMUL operands; STOREOUT source in a
+    int idx = -1;             // LOADIN: gin slot, LOADC: constant id, STOREOUT: gout slot
+    std::vector<Term> terms;  // LIN
+};
+
+class Dag {
+   public:
+    std::vector<Node> nodes;
+    int n_in = 0, n_out = 0;
+
+    int load_in(int slot);
+    int load_const(int cid);
+    int fmul(int a, int b);
+    int lin(std::vector<Term> terms);
+    void store_out(int node, int slot);
+
+    // Inlines single-use LIN nodes into their LIN consumers (bounded by LIN_MAX_TERMS),
+    // cancels x - x, and drops nodes nothing depends on.
+    void optimise();
+};
+
+struct Program {
+    std::string name;
+    int K = 0;
+    int n_lds_slots = 0;   // Fp slots of LDS each group needs
+    int n_tmp_slots = 0;   // Fp slots of the global spill array each group needs
+    int n_in = 0, n_out = 0;
+    std::vector<StepHdr> hdrs;
+    std::vector<OpDesc> descs;  // hdrs.size() * K
+    // statistics
+    int n_fmul = 0, n_lin = 0, n_lin_terms = 0, n_copy = 0;
+    int n_fmul_steps = 0, n_lin_steps = 0, n_copy_steps = 0;
+};
+
+// Schedules `dag` for groups of K lanes with at most `lds_slots` LDS slots per group.
+Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name);
+
+// ---- program builders (symbolic versions of the reference's native functions) ----
+// gin/gout slot numbering: G1 = {x, y}; G2 = {x.c0, x.c1, y.c0, y.c1};
+// Fq12 = ark tower order c0.c0.c0, c0.c0.c1, c0.c1.c0, ... c1.c2.c1.
+
+// multi_miller_loop_native for one pair, conjugated.      /root/reference/src/native/miller_loop.rs:121-162
+// gin: G1 (2) + G2 (4); gout: Fq12 (12).
+Dag build_miller();
+// G2Prepared::from: the 68 line coefficients.                /root/reference/src/native/miller_loop.rs:90-119
+// gin: G2 (4); gout: 68 * 6 (coefficient k, Fq2 j, component c at 6*k + 2*j + c).
+Dag build_g2_prepare();
+// ell(f, coeffs, p).                                         /root/reference/src/native/miller_loop.rs:185-194
+// gin: f (12) + coeff (6) + G1 (2); gout: f (12).
+Dag build_ell();
+// Final exponentiation, split around the one Fp inversion.   /root/reference/src/native/final_exponentiation.rs:8-78
+// part 1: gin f (12)           -> gout: [0] = norm in Fp, [1..] = values part 2 needs (FE_CARRY total)
+// part 2: gin = part 1's gout with slot 0 replaced by 1/norm -> gout: Fq12 (12)
+enum { FE_CARRY = 21 };
+Dag build_final_exp_part1();
+Dag build_final_exp_part2(bool cyclotomic_hard_part);
+// easy_part_native alone (part 2 of it; part 1 is build_final_exp_part1).
+Dag build_easy_part2();
+// hard_part_native on an arbitrary Fq12 (generic squarings).  gin 12 -> gout 12.
+Dag build_hard_part_generic();
+// Fq12 inverse of a canonical (non-Montgomery) value in MyFq12 order, as Fq12InverseGenerator
+// computes it.                                               /root/reference/src/fields/fq12_target.rs:374-397
+// part 1: gin x (12, canonical, MyFq12 order) -> gout [0] = norm, [1..FE_CARRY)
+// part 2: -> gout x^-1 (12, canonical, MyFq12 order)
+Dag build_fq12_inv_limbs_part1();
+Dag build_fq12_inv_limbs_part2();
+// Fq12 product (ark order in and out): gin a (12) + b (12) -> gout 12.
+Dag build_fq12_mul();
+// frobenius_map_native(a, power) for power in {1, 2}, ark order in/out.
+Dag build_frobenius(int power);
+
+}  // namespace bls381

@@ -1,0 +1,509 @@
+// Symbolic tower arithmetic and the program builders.  Formulas follow the reference where the
+// VALUE of an intermediate is observable (projective G2 steps, line coefficients: the Miller-loop
+// output before the final exponentiation must match arkworks bit for bit) and are free elsewhere
+// (Karatsuba, cyclotomic squaring), because field elements have one canonical representation.
+#include "tower_sym.h"
+
+#include <cassert>
+#include "bls381_constants.h"
+
+namespace bls381 {
+
+// ------------------------------------------------------------------ Fp
+SFp Tower::mat(SFp a) {
+    if (a.is_one()) return cst(C_ONE);
+    return a;
+}
+
+SFp Tower::lin(const std::vector<std::pair<SFp, int>>& terms) {
+    std::vector<Term> t;
+    for (auto& p : terms) {
+        if (p.first.is_zero()) continue;
+        SFp m = mat(p.first);
+        t.push_back(Term{m.id, p.second < 0});
+    }
+    if (t.empty()) return SZERO;
+    if (t.size() == 1 && !t[0].neg) return SFp{t[0].node};
+    return SFp{d_.lin(t)};
+}
+SFp Tower::lin(std::initializer_list<std::pair<SFp, int>> terms) {
+    return lin(std::vector<std::pair<SFp, int>>(terms));
+}
+
+SFp Tower::mul(SFp a, SFp b) {
+    if (a.is_zero() || b.is_zero()) return SZERO;
+    if (a.is_one()) return b;
+    if (b.is_one()) return a;
+    return SFp{d_.fmul(a.id, b.id)};
+}
+
+void Tower::out(SFp a, int slot) {
+    SFp m = a;
+    if (a.is_zero()) {
+        // 0 = 1 - 1 keeps the store path uniform
+        SFp one = cst(C_ONE);
+        m = SFp{d_.lin({Term{one.id, false}, Term{one.id, true}})};
+    } else {
+        m = mat(a);
+    }
+    d_.store_out(m.id, slot);
+}
+
+// ------------------------------------------------------------------ Fq2
+SFq2 Tower::lin2(const std::vector<std::pair<SFq2, int>>& terms) {
+    std::vector<std::pair<SFp, int>> t0, t1;
+    for (auto& p : terms) {
+        t0.push_back({p.first.c0, p.second});
+        t1.push_back({p.first.c1, p.second});
+    }
+    return {lin(t0), lin(t1)};
+}
+
+SFq2 Tower::mul(const SFq2& a, const SFq2& b) {
+    bool sparse = a.c0.is_zero() || a.c1.is_zero() || b.c0.is_zero() || b.c1.is_zero() ||
+                  a.c0.is_one() || b.c0.is_one();
+    if (sparse) {
+        SFp t00 = mul(a.c0, b.c0), t11 = mul(a.c1, b.c1);
+        SFp t01 = mul(a.c0, b.c1), t10 = mul(a.c1, b.c0);
+        return {sub(t00, t11), add(t01, t10)};
+    }
+    // Karatsuba: 3 products
+    SFp t0 = mul(a.c0, b.c0);
+    SFp t1 = mul(a.c1, b.c1);
+    SFp sa = add(a.c0, a.c1), sb = add(b.c0, b.c1);
+    SFp t2 = mul(sa, sb);
+    return {sub(t0, t1), lin({{t2, 1}, {t0, -1}, {t1, -1}})};
+}
+
+SFq2 Tower::sqr(const SFq2& a) {
+    if (a.c1.is_zero()) return {mul(a.c0, a.c0), SZERO};
+    if (a.c0.is_zero()) return {neg(mul(a.c1, a.c1)), SZERO};
+    SFp s = add(a.c0, a.c1), df = sub(a.c0, a.c1);
+    SFp c0 = mul(s, df);
+    SFp t = mul(mat(a.c0), a.c1);
+    return {c0, add(t, t)};
+}
+
+// ------------------------------------------------------------------ Fq6
+SFq6 Tower::mul(const SFq6& a, const SFq6& b) {
+    bool sparse = is_zero(a.c0) || is_zero(a.c1) || is_zero(a.c2) || is_zero(b.c0) || is_zero(b.c1) ||
+                  is_zero(b.c2);
+    if (sparse) {
+        // schoolbook with zero propagation
+        SFq2 p00 = mul(a.c0, b.c0), p01 = mul(a.c0, b.c1), p02 = mul(a.c0, b.c2);
+        SFq2 p10 = mul(a.c1, b.c0), p11 = mul(a.c1, b.c1), p12 = mul(a.c1, b.c2);
+        SFq2 p20 = mul(a.c2, b.c0), p21 = mul(a.c2, b.c1), p22 = mul(a.c2, b.c2);
+        SFq2 c0 = add(p00, mul_xi(add(p12, p21)));
+        SFq2 c1 = add(add(p01, p10), mul_xi(p22));
+        SFq2 c2 = add(add(p02, p11), p20);
+        return {c0, c1, c2};
+    }
+    // Karatsuba: 6 Fq2 products
+    SFq2 v0 = mul(a.c0, b.c0), v1 = mul(a.c1, b.c1), v2 = mul(a.c2, b.c2);
+    SFq2 t12 = mul(add(a.c1, a.c2), add(b.c1, b.c2));
+    SFq2 t01 = mul(add(a.c0, a.c1), add(b.c0, b.c1));
+    SFq2 t02 = mul(add(a.c0, a.c2), add(b.c0, b.c2));
+    SFq2 x = lin2({{t12, 1}, {v1, -1}, {v2, -1}});
+    SFq2 c0 = add(v0, mul_xi(x));
+    SFq2 c1 = add(lin2({{t01, 1}, {v0, -1}, {v1, -1}}), mul_xi(v2));
+    SFq2 c2 = lin2({{t02, 1}, {v0, -1}, {v2, -1}, {v1, 1}});
+    return {c0, c1, c2};
+}
+
+// Sparse products as restated at /root/reference/src/fields/fq6_target.rs:198-279.
+SFq6 Tower::mul_by_01(const SFq6& s, const SFq2& c0, const SFq2& c1) {
+    SFq2 a_a = mul(s.c0, c0);
+    SFq2 b_b = mul(s.c1, c1);
+    SFq2 t1 = add(mul_xi(mul(s.c2, c1)), a_a);
+    SFq2 t2 = lin2({{mul(add(c0, c1), add(s.c0, s.c1)), 1}, {a_a, -1}, {b_b, -1}});
+    SFq2 t3 = add(mul(s.c2, c0), b_b);
+    return {t1, t2, t3};
+}
+SFq6 Tower::mul_by_1(const SFq6& s, const SFq2& c1) {
+    // (s0 + s1 v + s2 v^2) * c1 v = xi s2 c1 + s0 c1 v + s1 c1 v^2
+    return {mul_xi(mul(s.c2, c1)), mul(s.c0, c1), mul(s.c1, c1)};
+}
+
+// ------------------------------------------------------------------ Fq12
+SFq12 Tower::mul(const SFq12& a, const SFq12& b) {
+    SFq6 m0 = mul(a.c0, b.c0);
+    SFq6 m1 = mul(a.c1, b.c1);
+    SFq6 m01 = mul(add(a.c0, a.c1), add(b.c0, b.c1));
+    SFq6 c1 = sub(sub(m01, m0), m1);
+    SFq6 c0 = add(m0, mul_v(m1));
+    return {c0, c1};
+}
+
+SFq12 Tower::sqr(const SFq12& a) {
+    // complex squaring: c0' = (c0 + c1)(c0 + v c1) - ab - v ab, c1' = 2ab, ab = c0 c1
+    SFq6 ab = mul(a.c0, a.c1);
+    SFq6 t = mul(add(a.c0, a.c1), add(a.c0, mul_v(a.c1)));
+    SFq6 c0 = sub(sub(t, ab), mul_v(ab));
+    SFq6 c1 = add(ab, ab);
+    return {c0, c1};
+}
+
+// /root/reference/src/fields/fq12_target.rs:258-295
+SFq12 Tower::mul_by_014(const SFq12& f, const SFq2& c0, const SFq2& c1, const SFq2& c4) {
+    SFq6 aa = mul_by_01(f.c0, c0, c1);
+    SFq6 bb = mul_by_1(f.c1, c4);
+    SFq2 o = add(c1, c4);
+    SFq6 s1 = mul_by_01(add(f.c1, f.c0), c0, o);
+    s1 = sub(sub(s1, aa), bb);
+    SFq6 s0 = add(mul_v(bb), aa);
+    return {s0, s1};
+}
+
+// Granger-Scott squaring in the cyclotomic subgroup (three Fq4 squarings).
+SFq12 Tower::cyclotomic_sqr(const SFq12& a) {
+    const SFq2 &r0 = a.c0.c0, &r4 = a.c0.c1, &r3 = a.c0.c2, &r2 = a.c1.c0, &r1 = a.c1.c1, &r5 = a.c1.c2;
+    auto fq4_sqr = [&](const SFq2& x, const SFq2& y, SFq2& t_even, SFq2& t_odd) {
+        // (x + y s)^2 with s^2 = xi:  t_even = x^2 + xi y^2,  t_odd = 2xy
+        SFq2 xy = mul(x, y);
+        SFq2 t = mul(add(x, y), add(mul_xi(y), x));
+        t_even = sub(sub(t, xy), mul_xi(xy));
+        t_odd = add(xy, xy);
+    };
+    SFq2 t0, t1, t2, t3, t4, t5;
+    fq4_sqr(r0, r1, t0, t1);
+    fq4_sqr(r2, r3, t2, t3);
+    fq4_sqr(r4, r5, t4, t5);
+    // z0 = 3 t0 - 2 r0 ; z1 = 3 t1 + 2 r1
+    SFq2 z0 = lin2({{t0, 1}, {t0, 1}, {t0, 1}, {r0, -1}, {r0, -1}});
+    SFq2 z1 = lin2({{t1, 1}, {t1, 1}, {t1, 1}, {r1, 1}, {r1, 1}});
+    // z2 = 3 xi t5 + 2 r2 ; z3 = 3 t4 - 2 r3
+    SFq2 x5 = mul_xi(t5);
+    SFq2 z2 = lin2({{x5, 1}, {x5, 1}, {x5, 1}, {r2, 1}, {r2, 1}});
+    SFq2 z3 = lin2({{t4, 1}, {t4, 1}, {t4, 1}, {r3, -1}, {r3, -1}});
+    // z4 = 3 t2 - 2 r4 ; z5 = 3 t3 + 2 r5
+    SFq2 z4 = lin2({{t2, 1}, {t2, 1}, {t2, 1}, {r4, -1}, {r4, -1}});
+    SFq2 z5 = lin2({{t3, 1}, {t3, 1}, {t3, 1}, {r5, 1}, {r5, 1}});
+    return {{z0, z4, z3}, {z2, z1, z5}};
+}
+
+// Coefficient i of w^i is conjugated (odd power) and multiplied by gamma_power^i.
+// /root/reference/src/native/fin_exp_helpers.rs:10-47; the constants are precomputed.
+SFq12 Tower::frobenius(const SFq12& a, int power) {
+    assert(power == 1 || power == 2);
+    // w-basis: A0 = c0.c0, A1 = c1.c0, A2 = c0.c1, A3 = c1.c1, A4 = c0.c2, A5 = c1.c2
+    const SFq2* A[6] = {&a.c0.c0, &a.c1.c0, &a.c0.c1, &a.c1.c1, &a.c0.c2, &a.c1.c2};
+    SFq2 B[6];
+    for (int i = 0; i < 6; i++) {
+        SFq2 x = *A[i];
+        if (power == 1) x = conj(x);
+        if (i == 0) {
+            B[i] = x;
+        } else if (power == 2) {
+            B[i] = mul_fp(x, cst(C_FROB2_BASE + (i - 1)));
+        } else {
+            SFq2 g{cst(C_FROB1_BASE + 2 * (i - 1)), cst(C_FROB1_BASE + 2 * (i - 1) + 1)};
+            B[i] = mul(x, g);
+        }
+    }
+    return {{B[0], B[2], B[4]}, {B[1], B[3], B[5]}};
+}
+
+// /root/reference/src/native/fin_exp_helpers.rs:60-82: plain MSB-first square-and-multiply by the
+// bits of |x| (its get_naf never emits a negative digit).
+SFq12 Tower::pow_x(const SFq12& a, bool cyclotomic) {
+    SFq12 res = a;
+    for (int i = 62; i >= 0; i--) {
+        res = cyclotomic ? cyclotomic_sqr(res) : sqr(res);
+        if ((BLS381_X >> i) & 1) res = mul(res, a);
+    }
+    return res;
+}
+
+// /root/reference/src/native/final_exponentiation.rs:44-72
+SFq12 Tower::hard_part(const SFq12& r_in, bool cyclotomic) {
+    SFq12 r = r_in;
+    SFq12 y0 = cyclotomic ? cyclotomic_sqr(r) : sqr(r);
+    SFq12 y1 = conj(pow_x(r, cyclotomic));
+    SFq12 y2 = conj(r);
+    y1 = mul(y1, y2);
+    y2 = conj(pow_x(y1, cyclotomic));
+    y1 = conj(y1);
+    y1 = mul(y1, y2);
+    y2 = conj(pow_x(y1, cyclotomic));
+    y1 = frobenius(y1, 1);
+    y1 = mul(y1, y2);
+    r = mul(r, y0);
+    y0 = conj(pow_x(y1, cyclotomic));
+    y2 = conj(pow_x(y0, cyclotomic));
+    y0 = frobenius(y1, 2);
+    y1 = conj(y1);
+    y1 = mul(y1, y2);
+    y1 = mul(y1, y0);
+    return mul(r, y1);
+}
+
+// a^-1 = conj-like: (c0 - c1 w) / (c0^2 - v c1^2); Fq6 and Fq2 inverses by norms.
+Tower::InvCarry Tower::inv_part1(const SFq12& a) {
+    SFq6 t = sub(mul(a.c0, a.c0), mul_v(mul(a.c1, a.c1)));
+    SFq2 s0 = sub(sqr(t.c0), mul_xi(mul(t.c1, t.c2)));
+    SFq2 s1 = sub(mul_xi(sqr(t.c2)), mul(t.c0, t.c1));
+    SFq2 s2 = sub(sqr(t.c1), mul(t.c0, t.c2));
+    SFq2 m = add(mul(t.c0, s0), mul_xi(add(mul(t.c2, s1), mul(t.c1, s2))));
+    SFp n = add(mul(m.c0, m.c0), mul(m.c1, m.c1));
+    return InvCarry{n, m, SFq6{s0, s1, s2}};
+}
+SFq12 Tower::inv_part2(const SFq12& a, const InvCarry& c, SFp norm_inv) {
+    SFq2 minv{mul(c.m.c0, norm_inv), neg(mul(c.m.c1, norm_inv))};
+    SFq6 tinv = mul_fq2(c.s, minv);
+    return {mul(a.c0, tinv), neg(mul(a.c1, tinv))};
+}
+
+// ------------------------------------------------------------------ pairing pieces
+// /root/reference/src/native/miller_loop.rs:50-69
+Tower::EllCoeff Tower::g2_double(G2Proj& r, SFp two_inv) {
+    SFq2 a = mul_fp(mul(r.x, r.y), two_inv);
+    SFq2 b = sqr(r.y);
+    SFq2 c = sqr(r.z);
+    // e = COEFF_B * 3c with COEFF_B = 4(1+u)
+    SFq2 c3 = lin2({{c, 1}, {c, 1}, {c, 1}});
+    SFq2 c12 = lin2({{c3, 1}, {c3, 1}, {c3, 1}, {c3, 1}});
+    SFq2 e = mul_xi(c12);
+    SFq2 f = lin2({{e, 1}, {e, 1}, {e, 1}});
+    SFq2 g = mul_fp(add(b, f), two_inv);
+    SFq2 h = sub(sqr(add(r.y, r.z)), add(b, c));
+    SFq2 i = sub(e, b);
+    SFq2 j = sqr(r.x);
+    SFq2 e_square = sqr(e);
+    SFq2 nx = mul(a, sub(b, f));
+    SFq2 ny = lin2({{sqr(g), 1}, {e_square, -1}, {e_square, -1}, {e_square, -1}});
+    SFq2 nz = mul(b, h);
+    r = G2Proj{nx, ny, nz};
+    return EllCoeff{i, lin2({{j, 1}, {j, 1}, {j, 1}}), neg(h)};
+}
+
+// /root/reference/src/native/miller_loop.rs:71-87
+Tower::EllCoeff Tower::g2_add(G2Proj& r, const SFq2& qx, const SFq2& qy) {
+    SFq2 theta = sub(r.y, mul(qy, r.z));
+    SFq2 lambda = sub(r.x, mul(qx, r.z));
+    SFq2 c = sqr(theta);
+    SFq2 d = sqr(lambda);
+    SFq2 e = mul(lambda, d);
+    SFq2 f = mul(r.z, c);
+    SFq2 g = mul(r.x, d);
+    SFq2 h = lin2({{e, 1}, {f, 1}, {g, -1}, {g, -1}});
+    SFq2 nx = mul(lambda, h);
+    SFq2 ny = sub(mul(theta, sub(g, h)), mul(e, r.y));
+    SFq2 nz = mul(r.z, e);
+    SFq2 j = sub(mul(theta, qx), mul(lambda, qy));
+    r = G2Proj{nx, ny, nz};
+    return EllCoeff{j, neg(theta), lambda};
+}
+
+// /root/reference/src/native/miller_loop.rs:185-194
+SFq12 Tower::ell(const SFq12& f, const EllCoeff& c, SFp px, SFp py) {
+    SFq2 c2 = mul_fp(c.c2, py);
+    SFq2 c1 = mul_fp(c.c1, px);
+    return mul_by_014(f, c.c0, c1, c2);
+}
+
+SFq12 Tower::in12(int base) {
+    SFp v[12];
+    for (int i = 0; i < 12; i++) v[i] = in(base + i);
+    return {{{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}}, {{v[6], v[7]}, {v[8], v[9]}, {v[10], v[11]}}};
+}
+void Tower::out12(const SFq12& a, int base) {
+    const SFp v[12] = {a.c0.c0.c0, a.c0.c0.c1, a.c0.c1.c0, a.c0.c1.c1, a.c0.c2.c0, a.c0.c2.c1,
+                       a.c1.c0.c0, a.c1.c0.c1, a.c1.c1.c0, a.c1.c1.c1, a.c1.c2.c0, a.c1.c2.c1};
+    for (int i = 0; i < 12; i++) out(v[i], base + i);
+}
+
+// ------------------------------------------------------------------ builders
+// The Miller loop walks the bits of |x| below the top one, MSB first
+// (BitIteratorBE::without_leading_zeros([BLS_X]).skip(1)): 63 doublings, 5 additions.
+static void miller_body(Tower& T, SFq12& f, bool emit_coeffs, int q_base, int p_base) {
+    Dag& d = T.dag();
+    (void)d;
+    auto load_q = [&](SFq2& qx, SFq2& qy) {
+        qx = SFq2{T.in(q_base + 0), T.in(q_base + 1)};
+        qy = SFq2{T.in(q_base + 2), T.in(q_base + 3)};
+    };
+    SFq2 qx, qy;
+    load_q(qx, qy);
+    Tower::G2Proj r{qx, qy, T.one2()};
+    int k = 0;
+    for (int i = 62; i >= 0; i--) {
+        SFp two_inv = T.cst(C_TWO_INV);
+        Tower::EllCoeff c = T.g2_double(r, two_inv);
+        if (emit_coeffs) {
+            T.out(c.c0.c0, 6 * k + 0); T.out(c.c0.c1, 6 * k + 1);
+            T.out(c.c1.c0, 6 * k + 2); T.out(c.c1.c1, 6 * k + 3);
+            T.out(c.c2.c0, 6 * k + 4); T.out(c.c2.c1, 6 * k + 5);
+        } else {
+            f = T.sqr(f);
+            f = T.ell(f, c, T.in(p_base + 0), T.in(p_base + 1));
+        }
+        k++;
+        if ((BLS381_X >> i) & 1) {
+            SFq2 ax, ay;
+            load_q(ax, ay);  // reloaded at each use: short live ranges
+            c = T.g2_add(r, ax, ay);
+            if (emit_coeffs) {
+                T.out(c.c0.c0, 6 * k + 0); T.out(c.c0.c1, 6 * k + 1);
+                T.out(c.c1.c0, 6 * k + 2); T.out(c.c1.c1, 6 * k + 3);
+                T.out(c.c2.c0, 6 * k + 4); T.out(c.c2.c1, 6 * k + 5);
+            } else {
+                f = T.ell(f, c, T.in(p_base + 0), T.in(p_base + 1));
+            }
+            k++;
+        }
+    }
+    assert(k == 68);
+}
+
+Dag build_miller() {
+    Dag d;
+    d.n_in = 6; d.n_out = 12;
+    Tower T(d);
+    SFq12 f = T.one12();
+    miller_body(T, f, false, /*q_base=*/2, /*p_base=*/0);
+    f = T.conj(f);  // BLS_X_IS_NEGATIVE, /root/reference/src/native/miller_loop.rs:157-159
+    T.out12(f, 0);
+    d.optimise();
+    return d;
+}
+
+Dag build_g2_prepare() {
+    Dag d;
+    d.n_in = 4; d.n_out = 68 * 6;
+    Tower T(d);
+    SFq12 f = T.one12();
+    miller_body(T, f, true, 0, 0);
+    d.optimise();
+    return d;
+}
+
+Dag build_ell() {
+    Dag d;
+    d.n_in = 20; d.n_out = 12;
+    Tower T(d);
+    SFq12 f = T.in12(0);
+    Tower::EllCoeff c{{T.in(12), T.in(13)}, {T.in(14), T.in(15)}, {T.in(16), T.in(17)}};
+    f = T.ell(f, c, T.in(18), T.in(19));
+    T.out12(f, 0);
+    d.optimise();
+    return d;
+}
+
+// Carry layout between the two halves: [0] norm / its inverse, [1..13) the input a,
+// [13..15) m, [15..21) s.
+static void store_carry(Tower& T, const SFq12& a, const Tower::InvCarry& c) {
+    T.out(c.norm, 0);
+    T.out12(a, 1);
+    T.out(c.m.c0, 13); T.out(c.m.c1, 14);
+    T.out(c.s.c0.c0, 15); T.out(c.s.c0.c1, 16);
+    T.out(c.s.c1.c0, 17); T.out(c.s.c1.c1, 18);
+    T.out(c.s.c2.c0, 19); T.out(c.s.c2.c1, 20);
+}
+static SFq12 load_carry_inverse(Tower& T, SFq12& a) {
+    SFp ninv = T.in(0);
+    a = T.in12(1);
+    Tower::InvCarry c;
+    c.norm = SZERO;
+    c.m = SFq2{T.in(13), T.in(14)};
+    c.s = SFq6{{T.in(15), T.in(16)}, {T.in(17), T.in(18)}, {T.in(19), T.in(20)}};
+    return T.inv_part2(a, c, ninv);
+}
+
+Dag build_final_exp_part1() {
+    Dag d;
+    d.n_in = 12; d.n_out = FE_CARRY;
+    Tower T(d);
+    SFq12 a = T.in12(0);
+    Tower::InvCarry c = T.inv_part1(a);
+    store_carry(T, a, c);
+    d.optimise();
+    return d;
+}
+
+// /root/reference/src/native/final_exponentiation.rs:8-19 then :44-72
+static SFq12 easy_part_tail(Tower& T) {
+    SFq12 a;
+    SFq12 ainv = load_carry_inverse(T, a);
+    SFq12 f2 = T.mul(T.conj(a), ainv);
+    SFq12 f3 = T.frobenius(f2, 2);
+    return T.mul(f3, f2);
+}
+
+Dag build_final_exp_part2(bool cyclotomic_hard_part) {
+    Dag d;
+    d.n_in = FE_CARRY; d.n_out = 12;
+    Tower T(d);
+    SFq12 f = easy_part_tail(T);
+    f = T.hard_part(f, cyclotomic_hard_part);
+    T.out12(f, 0);
+    d.optimise();
+    return d;
+}
+
+Dag build_easy_part2() {
+    Dag d;
+    d.n_in = FE_CARRY; d.n_out = 12;
+    Tower T(d);
+    T.out12(easy_part_tail(T), 0);
+    d.optimise();
+    return d;
+}
+
+Dag build_hard_part_generic() {
+    Dag d;
+    d.n_in = 12; d.n_out = 12;
+    Tower T(d);
+    T.out12(T.hard_part(T.in12(0), false), 0);
+    d.optimise();
+    return d;
+}
+
+// MyFq12 index k <-> ark flat index (/root/reference/src/utils/helpers.rs:39-41).
+static const int MY_TO_ARK[12] = {0, 6, 2, 8, 4, 10, 1, 7, 3, 9, 5, 11};
+
+Dag build_fq12_inv_limbs_part1() {
+    Dag d;
+    d.n_in = 12; d.n_out = FE_CARRY;
+    Tower T(d);
+    // canonical -> Montgomery: multiply by R^2
+    SFp v[12];
+    for (int k = 0; k < 12; k++) v[MY_TO_ARK[k]] = T.mul(T.in(k), T.cst(C_R2));
+    SFq12 a{{{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}}, {{v[6], v[7]}, {v[8], v[9]}, {v[10], v[11]}}};
+    Tower::InvCarry c = T.inv_part1(a);
+    store_carry(T, a, c);
+    d.optimise();
+    return d;
+}
+Dag build_fq12_inv_limbs_part2() {
+    Dag d;
+    d.n_in = FE_CARRY; d.n_out = 12;
+    Tower T(d);
+    SFq12 a;
+    SFq12 r = load_carry_inverse(T, a);
+    const SFp v[12] = {r.c0.c0.c0, r.c0.c0.c1, r.c0.c1.c0, r.c0.c1.c1, r.c0.c2.c0, r.c0.c2.c1,
+                       r.c1.c0.c0, r.c1.c0.c1, r.c1.c1.c0, r.c1.c1.c1, r.c1.c2.c0, r.c1.c2.c1};
+    // Montgomery -> canonical: multiply by the integer 1
+    for (int k = 0; k < 12; k++) T.out(T.mul(v[MY_TO_ARK[k]], T.cst(C_RAW_ONE)), k);
+    d.optimise();
+    return d;
+}
+
+Dag build_fq12_mul() {
+    Dag d;
+    d.n_in = 24; d.n_out = 12;
+    Tower T(d);
+    T.out12(T.mul(T.in12(0), T.in12(12)), 0);
+    d.optimise();
+    return d;
+}
+
+Dag build_frobenius(int power) {
+    Dag d;
+    d.n_in = 12; d.n_out = 12;
+    Tower T(d);
+    T.out12(T.frobenius(T.in12(0), power), 0);
+    d.optimise();
+    return d;
+}
+
+}  // namespace bls381

@@ -1,0 +1,219 @@
+"""Host-side mirror of the reference's `native` module on top of the C ABI.
+
+Names follow /root/reference/src/native/{pairing,miller_loop,final_exponentiation,fin_exp_helpers}.rs.
+Arrays are numpy uint64 in the layouts of include/bls381_hip.h (Fq = 6 x u64 Montgomery limbs):
+  g1: (n, 12)   g2: (n, 24)   fq12: (n, 72)   inf_flags: (n,) uint8 or None
+Every function raises Bls381Error where the reference panics or the GPU call fails.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Bls381Error, check, lib
+
+
+def _p64(a):
+    return a.ctypes.data_as(_lib.u64p)
+
+
+def _p32(a):
+    return a.ctypes.data_as(_lib.u32p)
+
+
+def _p8(a):
+    return None if a is None else a.ctypes.data_as(_lib.u8p)
+
+
+def _arr64(a, cols):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.ndim != 2 or a.shape[1] != cols:
+        raise ValueError("expected shape (n, %d), got %r" % (cols, a.shape))
+    return a
+
+
+def _flags(f, n):
+    if f is None:
+        return None
+    f = np.ascontiguousarray(f, dtype=np.uint8)
+    if f.shape != (n,):
+        raise ValueError("inf_flags must have shape (n,)")
+    return f
+
+
+class Context:
+    """One GPU.  lanes_per_group / lds_slots = 0 select the defaults."""
+
+    def __init__(self, device_id=0, lanes_per_group=0, lds_slots=0):
+        self._h = C.c_void_p()
+        check(lib.bls381_ctx_create_ex(C.byref(self._h), device_id, lanes_per_group, lds_slots))
+
+    def close(self):
+        if self._h:
+            lib.bls381_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- src/native/miller_loop.rs
+    def miller_loop_batch(self, g1, g2, inf_flags=None):
+        """multi_miller_loop_native([p], [q]) per pair (miller_loop.rs:121-162)."""
+        g1, g2 = _arr64(g1, 12), _arr64(g2, 24)
+        n = g1.shape[0]
+        if g2.shape[0] != n:
+            raise ValueError("zip_eq: length mismatch")  # the reference panics in zip_eq (miller_loop.rs:129)
+        fl = _flags(inf_flags, n)
+        out = np.empty((n, 72), dtype=np.uint64)
+        check(lib.bls381_miller_loop_batch(self._h, _p64(g1), _p64(g2), _p8(fl), n, _p64(out)))
+        return out
+
+    def multi_miller_loop_native(self, g1, g2, inf_flags=None):
+        """multi_miller_loop_native over all pairs: one Fq12 (miller_loop.rs:121-162)."""
+        g1, g2 = _arr64(g1, 12), _arr64(g2, 24)
+        n = g1.shape[0]
+        if g2.shape[0] != n:
+            raise ValueError("zip_eq: length mismatch")
+        fl = _flags(inf_flags, n)
+        out = np.empty(72, dtype=np.uint64)
+        check(lib.bls381_multi_miller_loop(self._h, _p64(g1), _p64(g2), _p8(fl), n, _p64(out)))
+        return out
+
+    def g2_prepare_batch(self, g2):
+        """G2Prepared::from(q).ell_coeffs (miller_loop.rs:90-119): (n, 68, 3, 2, 6) u64."""
+        g2 = _arr64(g2, 24)
+        n = g2.shape[0]
+        out = np.empty((n, 68 * 36), dtype=np.uint64)
+        check(lib.bls381_g2_prepare_batch(self._h, _p64(g2), n, _p64(out)))
+        return out.reshape(n, 68, 3, 2, 6)
+
+    def ell_batch(self, f, coeffs, g1):
+        """ell(f, coeffs, p) (miller_loop.rs:185-194)."""
+        f, coeffs, g1 = _arr64(f, 72), _arr64(coeffs, 36), _arr64(g1, 12)
+        n = f.shape[0]
+        out = np.empty((n, 72), dtype=np.uint64)
+        check(lib.bls381_ell_batch(self._h, _p64(f), _p64(coeffs), _p64(g1), n, _p64(out)))
+        return out
+
+    # ---- src/native/final_exponentiation.rs, fin_exp_helpers.rs
+    def final_exponentiation_batch(self, fq12):
+        fq12 = _arr64(fq12, 72)
+        n = fq12.shape[0]
+        out = np.empty((n, 72), dtype=np.uint64)
+        z = np.zeros(n, dtype=np.uint8)
+        check(lib.bls381_final_exp_batch(self._h, _p64(fq12), n, _p64(out), _p8(z)))
+        return out
+
+    def easy_part_batch(self, fq12):
+        fq12 = _arr64(fq12, 72)
+        n = fq12.shape[0]
+        out = np.empty((n, 72), dtype=np.uint64)
+        z = np.zeros(n, dtype=np.uint8)
+        check(lib.bls381_easy_part_batch(self._h, _p64(fq12), n, _p64(out), _p8(z)))
+        return out
+
+    def hard_part_batch(self, fq12):
+        fq12 = _arr64(fq12, 72)
+        n = fq12.shape[0]
+        out = np.empty((n, 72), dtype=np.uint64)
+        check(lib.bls381_hard_part_batch(self._h, _p64(fq12), n, _p64(out)))
+        return out
+
+    def frobenius_map_batch(self, fq12, power):
+        fq12 = _arr64(fq12, 72)
+        n = fq12.shape[0]
+        out = np.empty((n, 72), dtype=np.uint64)
+        check(lib.bls381_frobenius_batch(self._h, _p64(fq12), power, n, _p64(out)))
+        return out
+
+    def fq12_mul_batch(self, a, b):
+        a, b = _arr64(a, 72), _arr64(b, 72)
+        n = a.shape[0]
+        out = np.empty((n, 72), dtype=np.uint64)
+        check(lib.bls381_fq12_mul_batch(self._h, _p64(a), _p64(b), n, _p64(out)))
+        return out
+
+    # ---- src/native/pairing.rs
+    def pairing_batch(self, g1, g2, inf_flags=None):
+        """native_pairing([p], [q]) per pair (pairing.rs:8-13)."""
+        g1, g2 = _arr64(g1, 12), _arr64(g2, 24)
+        n = g1.shape[0]
+        if g2.shape[0] != n:
+            raise ValueError("zip_eq: length mismatch")
+        fl = _flags(inf_flags, n)
+        out = np.empty((n, 72), dtype=np.uint64)
+        check(lib.bls381_pairing_batch(self._h, _p64(g1), _p64(g2), _p8(fl), n, _p64(out)))
+        return out
+
+    def native_pairing(self, g1, g2, inf_flags=None):
+        """native_pairing over all pairs (pairing.rs:8-13): (Fq12, is_one)."""
+        g1, g2 = _arr64(g1, 12), _arr64(g2, 24)
+        n = g1.shape[0]
+        if g2.shape[0] != n:
+            raise ValueError("zip_eq: length mismatch")
+        fl = _flags(inf_flags, n)
+        out = np.empty(72, dtype=np.uint64)
+        one = C.c_int(0)
+        check(lib.bls381_multi_pairing(self._h, _p64(g1), _p64(g2), _p8(fl), n, _p64(out), C.byref(one)))
+        return out, bool(one.value)
+
+    def finish_multi_pairing(self, partials):
+        partials = _arr64(partials, 72)
+        out = np.empty(72, dtype=np.uint64)
+        one = C.c_int(0)
+        check(lib.bls381_finish_multi_pairing(self._h, _p64(partials), partials.shape[0], _p64(out), C.byref(one)))
+        return out, bool(one.value)
+
+    # ---- witness side (src/fields/fq12_target.rs:357-409, src/pairing.rs:13-20)
+    def fq12_inverse_limbs_batch(self, x):
+        x = np.ascontiguousarray(x, dtype=np.uint32)
+        if x.ndim != 2 or x.shape[1] != 144:
+            raise ValueError("expected shape (n, 144)")
+        n = x.shape[0]
+        inv = np.empty((n, 144), dtype=np.uint32)
+        err = np.zeros(n, dtype=np.uint8)
+        check(lib.bls381_fq12_inverse_limbs_batch(self._h, _p32(x), n, _p32(inv), _p8(err)))
+        return inv
+
+    def pairing_witness_batch(self, g1, g2):
+        g1, g2 = _arr64(g1, 12), _arr64(g2, 24)
+        n = g1.shape[0]
+        rows = lib.bls381_pairing_witness_rows()
+        trace = np.empty((n, rows, 12), dtype=np.uint32)
+        check(lib.bls381_pairing_witness_batch(self._h, _p64(g1), _p64(g2), n, _p32(trace)))
+        return trace
+
+    # ---- measurement
+    def last_timing(self):
+        ms = (C.c_float * 3)()
+        check(lib.bls381_last_timing(self._h, ms))
+        return list(ms)
+
+    def calibrate_mac_rate(self):
+        v = C.c_double(0)
+        check(lib.bls381_calibrate_mac_rate(self._h, C.byref(v)))
+        return v.value
+
+    @property
+    def handle(self):
+        return self._h
+
+
+def witness_rows():
+    return lib.bls381_pairing_witness_rows()
+
+
+def witness_kinds():
+    n = lib.bls381_pairing_witness_rows()
+    k = np.empty(n, dtype=np.uint8)
+    check(lib.bls381_pairing_witness_kinds(_p8(k), n))
+    return k
