@@ -125,10 +125,11 @@ int bls381_debug_program(const char* which, int lanes_per_group, int lds_slots, 
                          size_t capacity_steps, uint32_t info[8]);
 /* Constant table (C_COUNT x 12 u32). */
 int bls381_debug_constants(uint32_t* out, size_t capacity_fp);
-/* Timing of the most recent batch call on this context, from HIP events on the context's stream:
- * ms[0] = Miller kernel, ms[1] = final-exponentiation kernels (incl. inversion), ms[2] = whole call
- * on the device including layout conversion. */
-int bls381_last_timing(bls381_ctx*, float ms[3]);
+/* Timing of the most recent pairing / Miller-loop / final-exponentiation batch call on this context
+ * (its last 65,536-element chunk), from HIP events on the context's stream, in milliseconds:
+ * ms[0] = Miller-loop kernel, ms[1] = final exponentiation part 1 + Fp inversion kernel,
+ * ms[2] = final exponentiation part 2 kernel, ms[3] = whole device-side call incl. layout conversion. */
+int bls381_last_timing(bls381_ctx*, float ms[4]);
 /* Sustained v_mad_u64_u32 rate of the device in multiply-accumulates per second (calibration kernel). */
 int bls381_calibrate_mac_rate(bls381_ctx*, double* mac_per_s);
 

@@ -1,0 +1,416 @@
+/* CPU oracle in C: restatement of the reference's native pairing path on 6 x u64 Montgomery limbs.
+ *
+ * TEST INFRASTRUCTURE ONLY: linked by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg, never by the shipped library.  "parity unpinned" against arkworks (the reference holds no
+ * golden vectors and no Rust toolchain exists here); pinned against oracle/py/bls381_ref.py, which
+ * is itself pinned by bilinearity, e^r = 1 and final_exp(x) = x^(3(p^12-1)/r).
+ *
+ * Algorithms follow the reference as written:
+ *   G2 steps / prepare / ell / Miller loop   /root/reference/src/native/miller_loop.rs:50-194
+ *   MyFq12 (flat, 144-multiplication product) /root/reference/src/utils/helpers.rs:8-152
+ *   Frobenius, pow_native, conjugate          /root/reference/src/native/fin_exp_helpers.rs:10-142
+ *   easy / hard part, final_exponentiation    /root/reference/src/native/final_exponentiation.rs:8-78
+ * One deliberate difference, stated wherever timings are reported: the Frobenius constants are
+ * computed once at start-up; the reference recomputes them by exponentiation on every call
+ * (fin_exp_helpers.rs:20, :49-58).
+ * The tower arithmetic itself (Fq2/Fq6/Fq12 mul, square, inverse, mul_by_014) lives in ark-ff
+ * 0.4.2 / ark-bls12-381 0.4.0, absent from the reference tree; textbook Karatsuba forms are used.
+ */
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+#include "oracle_constants.h"
+
+typedef unsigned __int128 u128;
+typedef struct { uint64_t l[6]; } fp;
+typedef struct { fp c0, c1; } fp2;
+typedef struct { fp2 c0, c1, c2; } fp6;
+typedef struct { fp6 c0, c1; } fp12;
+typedef struct { fp c[12]; } myfp12;
+
+#define BLS_X 0xd201000000010000ull
+
+/* ------------------------------------------------------------------ Fp */
+static inline int fp_is_zero(const fp* a) { uint64_t x = 0; for (int i = 0; i < 6; i++) x |= a->l[i]; return x == 0; }
+static inline void fp_set(fp* r, const uint64_t* v) { memcpy(r->l, v, 48); }
+static inline int fp_geq_p(const uint64_t* a) {
+    for (int i = 5; i >= 0; i--) { if (a[i] > ORC_P[i]) return 1; if (a[i] < ORC_P[i]) return 0; }
+    return 1;
+}
+static inline void fp_add(fp* r, const fp* a, const fp* b) {
+    u128 c = 0; uint64_t t[6];
+    for (int i = 0; i < 6; i++) { c += (u128)a->l[i] + b->l[i]; t[i] = (uint64_t)c; c >>= 64; }
+    if (fp_geq_p(t)) { u128 bw = 0; for (int i = 0; i < 6; i++) { u128 d = (u128)t[i] - ORC_P[i] - (uint64_t)bw; t[i] = (uint64_t)d; bw = (d >> 64) & 1; } }
+    memcpy(r->l, t, 48);
+}
+static inline void fp_sub(fp* r, const fp* a, const fp* b) {
+    uint64_t t[6]; u128 bw = 0;
+    for (int i = 0; i < 6; i++) { u128 d = (u128)a->l[i] - b->l[i] - (uint64_t)bw; t[i] = (uint64_t)d; bw = (d >> 64) & 1; }
+    if (bw) { u128 c = 0; for (int i = 0; i < 6; i++) { c += (u128)t[i] + ORC_P[i]; t[i] = (uint64_t)c; c >>= 64; } }
+    memcpy(r->l, t, 48);
+}
+static inline void fp_neg(fp* r, const fp* a) { fp z; memset(&z, 0, sizeof z); fp_sub(r, &z, a); }
+static inline void fp_dbl(fp* r, const fp* a) { fp_add(r, a, a); }
+static void fp_mul(fp* r, const fp* a, const fp* b) {
+    uint64_t t[8] = {0};
+    for (int i = 0; i < 6; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 6; j++) { c += (u128)a->l[j] * b->l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+        c += t[6]; t[6] = (uint64_t)c; t[7] = (uint64_t)(c >> 64);
+        uint64_t m = t[0] * ORC_N0;
+        c = (u128)m * ORC_P[0] + t[0]; c >>= 64;
+        for (int j = 1; j < 6; j++) { c += (u128)m * ORC_P[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+        c += t[6]; t[5] = (uint64_t)c; t[6] = t[7] + (uint64_t)(c >> 64);
+    }
+    if (t[6] || fp_geq_p(t)) { u128 bw = 0; for (int i = 0; i < 6; i++) { u128 d = (u128)t[i] - ORC_P[i] - (uint64_t)bw; t[i] = (uint64_t)d; bw = (d >> 64) & 1; } }
+    memcpy(r->l, t, 48);
+}
+static inline void fp_sqr(fp* r, const fp* a) { fp_mul(r, a, a); }
+static void fp_inv(fp* r, const fp* a) {
+    fp x; fp_set(&x, ORC_ONE);
+    for (int w = 5; w >= 0; w--)
+        for (int b = 63; b >= 0; b--) { fp_sqr(&x, &x); if ((ORC_P_MINUS_2[w] >> b) & 1) fp_mul(&x, &x, a); }
+    *r = x;
+}
+
+/* ------------------------------------------------------------------ Fp2 */
+static inline void fp2_add(fp2* r, const fp2* a, const fp2* b) { fp_add(&r->c0, &a->c0, &b->c0); fp_add(&r->c1, &a->c1, &b->c1); }
+static inline void fp2_sub(fp2* r, const fp2* a, const fp2* b) { fp_sub(&r->c0, &a->c0, &b->c0); fp_sub(&r->c1, &a->c1, &b->c1); }
+static inline void fp2_neg(fp2* r, const fp2* a) { fp_neg(&r->c0, &a->c0); fp_neg(&r->c1, &a->c1); }
+static inline void fp2_dbl(fp2* r, const fp2* a) { fp2_add(r, a, a); }
+static inline void fp2_conj(fp2* r, const fp2* a) { r->c0 = a->c0; fp_neg(&r->c1, &a->c1); }
+static void fp2_mul(fp2* r, const fp2* a, const fp2* b) {
+    fp t0, t1, t2, s, u;
+    fp_mul(&t0, &a->c0, &b->c0); fp_mul(&t1, &a->c1, &b->c1);
+    fp_add(&s, &a->c0, &a->c1); fp_add(&u, &b->c0, &b->c1); fp_mul(&t2, &s, &u);
+    fp_sub(&r->c0, &t0, &t1); fp_sub(&t2, &t2, &t0); fp_sub(&r->c1, &t2, &t1);
+}
+static void fp2_sqr(fp2* r, const fp2* a) {
+    fp s, d, t;
+    fp_add(&s, &a->c0, &a->c1); fp_sub(&d, &a->c0, &a->c1); fp_mul(&t, &a->c0, &a->c1);
+    fp_mul(&r->c0, &s, &d); fp_dbl(&r->c1, &t);
+}
+static inline void fp2_mul_fp(fp2* r, const fp2* a, const fp* s) { fp_mul(&r->c0, &a->c0, s); fp_mul(&r->c1, &a->c1, s); }
+static inline void fp2_mul_xi(fp2* r, const fp2* a) { fp t; fp_sub(&t, &a->c0, &a->c1); fp_add(&r->c1, &a->c0, &a->c1); r->c0 = t; }
+static void fp2_inv(fp2* r, const fp2* a) {
+    fp n, t; fp_sqr(&n, &a->c0); fp_sqr(&t, &a->c1); fp_add(&n, &n, &t); fp_inv(&n, &n);
+    fp_mul(&r->c0, &a->c0, &n); fp_mul(&t, &a->c1, &n); fp_neg(&r->c1, &t);
+}
+
+/* ------------------------------------------------------------------ Fp6 */
+static inline void fp6_add(fp6* r, const fp6* a, const fp6* b) { fp2_add(&r->c0, &a->c0, &b->c0); fp2_add(&r->c1, &a->c1, &b->c1); fp2_add(&r->c2, &a->c2, &b->c2); }
+static inline void fp6_sub(fp6* r, const fp6* a, const fp6* b) { fp2_sub(&r->c0, &a->c0, &b->c0); fp2_sub(&r->c1, &a->c1, &b->c1); fp2_sub(&r->c2, &a->c2, &b->c2); }
+static inline void fp6_neg(fp6* r, const fp6* a) { fp2_neg(&r->c0, &a->c0); fp2_neg(&r->c1, &a->c1); fp2_neg(&r->c2, &a->c2); }
+static inline void fp6_mul_v(fp6* r, const fp6* a) { fp2 t; fp2_mul_xi(&t, &a->c2); r->c2 = a->c1; r->c1 = a->c0; r->c0 = t; }
+static void fp6_mul(fp6* r, const fp6* a, const fp6* b) {
+    fp2 v0, v1, v2, t, u, x, c0, c1, c2;
+    fp2_mul(&v0, &a->c0, &b->c0); fp2_mul(&v1, &a->c1, &b->c1); fp2_mul(&v2, &a->c2, &b->c2);
+    fp2_add(&t, &a->c1, &a->c2); fp2_add(&u, &b->c1, &b->c2); fp2_mul(&x, &t, &u); fp2_sub(&x, &x, &v1); fp2_sub(&x, &x, &v2); fp2_mul_xi(&x, &x); fp2_add(&c0, &x, &v0);
+    fp2_add(&t, &a->c0, &a->c1); fp2_add(&u, &b->c0, &b->c1); fp2_mul(&x, &t, &u); fp2_sub(&x, &x, &v0); fp2_sub(&x, &x, &v1); fp2_mul_xi(&t, &v2); fp2_add(&c1, &x, &t);
+    fp2_add(&t, &a->c0, &a->c2); fp2_add(&u, &b->c0, &b->c2); fp2_mul(&x, &t, &u); fp2_sub(&x, &x, &v0); fp2_sub(&x, &x, &v2); fp2_add(&c2, &x, &v1);
+    r->c0 = c0; r->c1 = c1; r->c2 = c2;
+}
+/* sparse products, as restated at /root/reference/src/fields/fq6_target.rs:198-279 */
+static void fp6_mul_by_01(fp6* r, const fp6* s, const fp2* c0, const fp2* c1) {
+    fp2 a_a, b_b, t1, t2, t3, x, y;
+    fp2_mul(&a_a, &s->c0, c0); fp2_mul(&b_b, &s->c1, c1);
+    fp2_mul(&t1, &s->c2, c1); fp2_mul_xi(&t1, &t1); fp2_add(&t1, &t1, &a_a);
+    fp2_add(&x, c0, c1); fp2_add(&y, &s->c0, &s->c1); fp2_mul(&t2, &x, &y); fp2_sub(&t2, &t2, &a_a); fp2_sub(&t2, &t2, &b_b);
+    fp2_mul(&t3, &s->c2, c0); fp2_add(&t3, &t3, &b_b);
+    r->c0 = t1; r->c1 = t2; r->c2 = t3;
+}
+static void fp6_mul_by_1(fp6* r, const fp6* s, const fp2* c1) {
+    fp2 b_b, t1, t2, tmp;
+    fp2_mul(&b_b, &s->c1, c1);
+    fp2_add(&tmp, &s->c1, &s->c2); fp2_mul(&t1, c1, &tmp); fp2_sub(&t1, &t1, &b_b); fp2_mul_xi(&t1, &t1);
+    fp2_add(&tmp, &s->c0, &s->c1); fp2_mul(&t2, c1, &tmp); fp2_sub(&t2, &t2, &b_b);
+    r->c0 = t1; r->c1 = t2; r->c2 = b_b;
+}
+static void fp6_inv(fp6* r, const fp6* a) {
+    fp2 t0, t1, t2, x, y, n;
+    fp2_sqr(&t0, &a->c0); fp2_mul(&x, &a->c1, &a->c2); fp2_mul_xi(&x, &x); fp2_sub(&t0, &t0, &x);
+    fp2_sqr(&t1, &a->c2); fp2_mul_xi(&t1, &t1); fp2_mul(&x, &a->c0, &a->c1); fp2_sub(&t1, &t1, &x);
+    fp2_sqr(&t2, &a->c1); fp2_mul(&x, &a->c0, &a->c2); fp2_sub(&t2, &t2, &x);
+    fp2_mul(&x, &a->c2, &t1); fp2_mul(&y, &a->c1, &t2); fp2_add(&x, &x, &y); fp2_mul_xi(&x, &x); fp2_mul(&n, &a->c0, &t0); fp2_add(&n, &n, &x);
+    fp2_inv(&n, &n);
+    fp2_mul(&r->c0, &t0, &n); fp2_mul(&r->c1, &t1, &n); fp2_mul(&r->c2, &t2, &n);
+}
+
+/* ------------------------------------------------------------------ Fp12 */
+static void fp12_mul(fp12* r, const fp12* a, const fp12* b) {
+    fp6 m0, m1, s, t, m01;
+    fp6_mul(&m0, &a->c0, &b->c0); fp6_mul(&m1, &a->c1, &b->c1);
+    fp6_add(&s, &a->c0, &a->c1); fp6_add(&t, &b->c0, &b->c1); fp6_mul(&m01, &s, &t);
+    fp6_sub(&m01, &m01, &m0); fp6_sub(&r->c1, &m01, &m1);
+    fp6_mul_v(&t, &m1); fp6_add(&r->c0, &m0, &t);
+}
+static void fp12_sqr(fp12* r, const fp12* a) {
+    fp6 ab, s, t, u;
+    fp6_mul(&ab, &a->c0, &a->c1);
+    fp6_add(&s, &a->c0, &a->c1); fp6_mul_v(&t, &a->c1); fp6_add(&t, &t, &a->c0); fp6_mul(&u, &s, &t);
+    fp6_sub(&u, &u, &ab); fp6_mul_v(&t, &ab); fp6_sub(&r->c0, &u, &t); fp6_add(&r->c1, &ab, &ab);
+}
+static inline void fp12_conj(fp12* r, const fp12* a) { r->c0 = a->c0; fp6_neg(&r->c1, &a->c1); }
+static int fp12_inv(fp12* r, const fp12* a) {
+    fp6 t0, t1;
+    fp6_mul(&t0, &a->c0, &a->c0); fp6_mul(&t1, &a->c1, &a->c1); fp6_mul_v(&t1, &t1); fp6_sub(&t0, &t0, &t1);
+    const fp* z = (const fp*)&t0; int zero = 1; for (int i = 0; i < 6; i++) if (!fp_is_zero(&z[i])) zero = 0;
+    if (zero) return -1;
+    fp6_inv(&t0, &t0);
+    fp6_mul(&r->c0, &a->c0, &t0); fp6_mul(&t1, &a->c1, &t0); fp6_neg(&r->c1, &t1);
+    return 0;
+}
+/* /root/reference/src/fields/fq12_target.rs:258-295 */
+static void fp12_mul_by_014(fp12* f, const fp2* c0, const fp2* c1, const fp2* c4) {
+    fp6 aa, bb, s1, t; fp2 o;
+    fp6_mul_by_01(&aa, &f->c0, c0, c1);
+    fp6_mul_by_1(&bb, &f->c1, c4);
+    fp2_add(&o, c1, c4);
+    fp6_add(&s1, &f->c1, &f->c0);
+    fp6_mul_by_01(&s1, &s1, c0, &o);
+    fp6_sub(&s1, &s1, &aa); fp6_sub(&s1, &s1, &bb);
+    fp6_mul_v(&t, &bb); fp6_add(&f->c0, &t, &aa);
+    f->c1 = s1;
+}
+
+/* ------------------------------------------------------------------ MyFq12 (src/utils/helpers.rs) */
+static const int ARK_TO_MY[12] = {0, 6, 2, 8, 4, 10, 1, 7, 3, 9, 5, 11};
+static void my_from_fp12(myfp12* m, const fp12* a) { const fp* f = (const fp*)a; for (int k = 0; k < 12; k++) m->c[k] = f[ARK_TO_MY[k]]; }
+static void my_to_fp12(fp12* a, const myfp12* m) { fp* f = (fp*)a; for (int k = 0; k < 12; k++) f[ARK_TO_MY[k]] = m->c[k]; }
+/* helpers.rs:90-152: schoolbook, 144 Fq multiplications */
+static void my_mul(myfp12* r, const myfp12* a, const myfp12* b) {
+    fp a0b0[11], a0b1[11], a1b0[11], a1b1[11], t;
+    memset(a0b0, 0, sizeof a0b0); memset(a0b1, 0, sizeof a0b1); memset(a1b0, 0, sizeof a1b0); memset(a1b1, 0, sizeof a1b1);
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+            fp_mul(&t, &a->c[i], &b->c[j]); fp_add(&a0b0[i + j], &a0b0[i + j], &t);
+            fp_mul(&t, &a->c[i], &b->c[j + 6]); fp_add(&a0b1[i + j], &a0b1[i + j], &t);
+            fp_mul(&t, &a->c[i + 6], &b->c[j]); fp_add(&a1b0[i + j], &a1b0[i + j], &t);
+            fp_mul(&t, &a->c[i + 6], &b->c[j + 6]); fp_add(&a1b1[i + j], &a1b1[i + j], &t);
+        }
+    fp m[11], pl[11];
+    for (int i = 0; i < 11; i++) { fp_sub(&m[i], &a0b0[i], &a1b1[i]); fp_add(&pl[i], &a0b1[i], &a1b0[i]); }
+    myfp12 o;
+    for (int i = 0; i < 6; i++) {
+        if (i < 5) { fp_add(&t, &m[i], &m[i + 6]); fp_sub(&o.c[i], &t, &pl[i + 6]); } else o.c[i] = m[i];
+    }
+    for (int i = 0; i < 6; i++) {
+        if (i < 5) { fp_add(&t, &pl[i], &m[i + 6]); fp_add(&o.c[i + 6], &t, &pl[i + 6]); } else o.c[i + 6] = pl[i];
+    }
+    *r = o;
+}
+/* fin_exp_helpers.rs:132-142 */
+static void my_conj(myfp12* r, const myfp12* a) { for (int i = 0; i < 12; i++) { if (i % 2 == 0) r->c[i] = a->c[i]; else fp_neg(&r->c[i], &a->c[i]); } }
+
+static const uint64_t* FROB_C0[3][6] = {{0}, {ORC_FROB1_0_C0, ORC_FROB1_1_C0, ORC_FROB1_2_C0, ORC_FROB1_3_C0, ORC_FROB1_4_C0, ORC_FROB1_5_C0},
+                                        {ORC_FROB2_0_C0, ORC_FROB2_1_C0, ORC_FROB2_2_C0, ORC_FROB2_3_C0, ORC_FROB2_4_C0, ORC_FROB2_5_C0}};
+static const uint64_t* FROB_C1[3][6] = {{0}, {ORC_FROB1_0_C1, ORC_FROB1_1_C1, ORC_FROB1_2_C1, ORC_FROB1_3_C1, ORC_FROB1_4_C1, ORC_FROB1_5_C1},
+                                        {ORC_FROB2_0_C1, ORC_FROB2_1_C1, ORC_FROB2_2_C1, ORC_FROB2_3_C1, ORC_FROB2_4_C1, ORC_FROB2_5_C1}};
+/* fin_exp_helpers.rs:10-47, power in {1,2}; constants precomputed (see header) */
+static void my_frobenius(myfp12* r, const myfp12* a, int power) {
+    myfp12 o;
+    for (int i = 0; i < 6; i++) {
+        fp2 x, g, y;
+        x.c0 = a->c[i]; x.c1 = a->c[i + 6];
+        if (power % 2) fp2_conj(&x, &x);
+        if (i == 0) y = x;
+        else { fp_set(&g.c0, FROB_C0[power][i]); fp_set(&g.c1, FROB_C1[power][i]); fp2_mul(&y, &x, &g); }
+        o.c[i] = y.c0; o.c[i + 6] = y.c1;
+    }
+    *r = o;
+}
+/* fin_exp_helpers.rs:60-82: MSB-first square-and-multiply with MyFq12::mul */
+static void my_pow_x(myfp12* r, const myfp12* a) {
+    myfp12 res = *a;
+    for (int i = 62; i >= 0; i--) { my_mul(&res, &res, &res); if ((BLS_X >> i) & 1) my_mul(&res, &res, a); }
+    *r = res;
+}
+
+/* ------------------------------------------------------------------ Miller loop (src/native/miller_loop.rs) */
+typedef struct { fp2 x, y, z; } g2proj;
+typedef struct { fp2 c0, c1, c2; } ellcoeff;
+static void g2_double(g2proj* r, ellcoeff* out, const fp* two_inv) { /* :50-69 */
+    fp2 a, b, c, e, f, g, h, i, j, es, t, u;
+    fp2_mul(&a, &r->x, &r->y); fp2_mul_fp(&a, &a, two_inv);
+    fp2_sqr(&b, &r->y); fp2_sqr(&c, &r->z);
+    fp2_dbl(&t, &c); fp2_add(&t, &t, &c);                      /* 3c */
+    fp2_dbl(&u, &t); fp2_dbl(&u, &u); fp2_mul_xi(&e, &u);      /* COEFF_B * 3c, COEFF_B = 4(1+u) */
+    fp2_dbl(&f, &e); fp2_add(&f, &f, &e);
+    fp2_add(&g, &b, &f); fp2_mul_fp(&g, &g, two_inv);
+    fp2_add(&t, &r->y, &r->z); fp2_sqr(&h, &t); fp2_add(&t, &b, &c); fp2_sub(&h, &h, &t);
+    fp2_sub(&i, &e, &b);
+    fp2_sqr(&j, &r->x);
+    fp2_sqr(&es, &e);
+    fp2_sub(&t, &b, &f); fp2_mul(&r->x, &a, &t);
+    fp2_sqr(&t, &g); fp2_dbl(&u, &es); fp2_add(&u, &u, &es); fp2_sub(&r->y, &t, &u);
+    fp2_mul(&r->z, &b, &h);
+    out->c0 = i; fp2_dbl(&t, &j); fp2_add(&out->c1, &t, &j); fp2_neg(&out->c2, &h);
+}
+static void g2_add(g2proj* r, ellcoeff* out, const fp2* qx, const fp2* qy) { /* :71-87 */
+    fp2 theta, lambda, c, d, e, f, g, h, t, u, j;
+    fp2_mul(&t, qy, &r->z); fp2_sub(&theta, &r->y, &t);
+    fp2_mul(&t, qx, &r->z); fp2_sub(&lambda, &r->x, &t);
+    fp2_sqr(&c, &theta); fp2_sqr(&d, &lambda);
+    fp2_mul(&e, &lambda, &d); fp2_mul(&f, &r->z, &c); fp2_mul(&g, &r->x, &d);
+    fp2_add(&h, &e, &f); fp2_dbl(&t, &g); fp2_sub(&h, &h, &t);
+    fp2 nx, ny, nz;
+    fp2_mul(&nx, &lambda, &h);
+    fp2_sub(&t, &g, &h); fp2_mul(&t, &theta, &t); fp2_mul(&u, &e, &r->y); fp2_sub(&ny, &t, &u);
+    fp2_mul(&nz, &r->z, &e);
+    fp2_mul(&t, &theta, qx); fp2_mul(&u, &lambda, qy); fp2_sub(&j, &t, &u);
+    r->x = nx; r->y = ny; r->z = nz;
+    out->c0 = j; fp2_neg(&out->c1, &theta); out->c2 = lambda;
+}
+/* :90-119; coeffs[68] */
+static void g2_prepare(ellcoeff* coeffs, const fp2* qx, const fp2* qy) {
+    fp two_inv; fp_set(&two_inv, ORC_TWO_INV);
+    g2proj r; r.x = *qx; r.y = *qy; memset(&r.z, 0, sizeof r.z); fp_set(&r.z.c0, ORC_ONE);
+    int k = 0;
+    for (int i = 62; i >= 0; i--) {
+        g2_double(&r, &coeffs[k++], &two_inv);
+        if ((BLS_X >> i) & 1) g2_add(&r, &coeffs[k++], qx, qy);
+    }
+}
+static void ell(fp12* f, const ellcoeff* c, const fp* px, const fp* py) { /* :185-194 */
+    fp2 c1, c2;
+    fp2_mul_fp(&c2, &c->c2, py); fp2_mul_fp(&c1, &c->c1, px);
+    fp12_mul_by_014(f, &c->c0, &c1, &c2);
+}
+static void fp12_one(fp12* f) { memset(f, 0, sizeof *f); fp_set(&f->c0.c0.c0, ORC_ONE); }
+
+/* multi_miller_loop_native (:121-162): chunks of 4 pairs share the squarings */
+void orc_multi_miller_loop(const uint64_t* g1, const uint64_t* g2, const uint8_t* flags, size_t n, uint64_t* out) {
+    ellcoeff (*coeffs)[68] = malloc(sizeof(ellcoeff[68]) * 4);
+    fp px[4], py[4];
+    fp12 total; fp12_one(&total);
+    size_t i = 0;
+    while (i < n) {
+        int m = 0;
+        while (i < n && m < 4) {
+            if (!(flags && flags[i])) {
+                fp2 qx, qy;
+                fp_set(&px[m], g1 + i * 12); fp_set(&py[m], g1 + i * 12 + 6);
+                fp_set(&qx.c0, g2 + i * 24); fp_set(&qx.c1, g2 + i * 24 + 6); fp_set(&qy.c0, g2 + i * 24 + 12); fp_set(&qy.c1, g2 + i * 24 + 18);
+                g2_prepare(coeffs[m], &qx, &qy);
+                m++;
+            }
+            i++;
+        }
+        if (m == 0) continue;
+        fp12 f; fp12_one(&f);
+        int k = 0;
+        for (int b = 62; b >= 0; b--) {
+            fp12_sqr(&f, &f);
+            for (int j = 0; j < m; j++) ell(&f, &coeffs[j][k], &px[j], &py[j]);
+            k++;
+            if ((BLS_X >> b) & 1) { for (int j = 0; j < m; j++) ell(&f, &coeffs[j][k], &px[j], &py[j]); k++; }
+        }
+        fp12_mul(&total, &total, &f);
+    }
+    fp12_conj(&total, &total);
+    memcpy(out, &total, 576);
+    free(coeffs);
+}
+
+/* ------------------------------------------------------------------ final exponentiation */
+static int easy_part(myfp12* r, const myfp12* a) { /* final_exponentiation.rs:8-19 */
+    myfp12 f1, f2, f3; fp12 x, y, inv;
+    my_conj(&f1, a);
+    my_to_fp12(&x, &f1); my_to_fp12(&y, a);
+    if (fp12_inv(&inv, &y)) return -1;
+    fp12_mul(&x, &x, &inv); my_from_fp12(&f2, &x);
+    my_frobenius(&f3, &f2, 2);
+    my_mul(r, &f3, &f2);
+    return 0;
+}
+static void pow_x_fp12(fp12* r, const fp12* a) { myfp12 m, o; my_from_fp12(&m, a); my_pow_x(&o, &m); my_to_fp12(r, &o); }
+static void frob_fp12(fp12* r, const fp12* a, int p) { myfp12 m, o; my_from_fp12(&m, a); my_frobenius(&o, &m, p); my_to_fp12(r, &o); }
+static void hard_part(fp12* out, const fp12* rin) { /* :44-72 */
+    fp12 r = *rin, y0, y1, y2;
+    fp12_sqr(&y0, &r);
+    pow_x_fp12(&y1, &r); fp12_conj(&y1, &y1);
+    fp12_conj(&y2, &r);
+    fp12_mul(&y1, &y1, &y2);
+    pow_x_fp12(&y2, &y1); fp12_conj(&y2, &y2);
+    fp12_conj(&y1, &y1);
+    fp12_mul(&y1, &y1, &y2);
+    pow_x_fp12(&y2, &y1); fp12_conj(&y2, &y2);
+    frob_fp12(&y1, &y1, 1);
+    fp12_mul(&y1, &y1, &y2);
+    fp12_mul(&r, &r, &y0);
+    pow_x_fp12(&y0, &y1); fp12_conj(&y0, &y0);
+    pow_x_fp12(&y2, &y0); fp12_conj(&y2, &y2);
+    frob_fp12(&y0, &y1, 2);
+    fp12_conj(&y1, &y1);
+    fp12_mul(&y1, &y1, &y2);
+    fp12_mul(&y1, &y1, &y0);
+    fp12_mul(out, &r, &y1);
+}
+/* final_exponentiation (:74-78) on ark-ordered limbs; returns -1 on zero input */
+int orc_final_exponentiation(const uint64_t* in, uint64_t* out) {
+    fp12 a, f; myfp12 m, e;
+    memcpy(&a, in, 576); my_from_fp12(&m, &a);
+    if (easy_part(&e, &m)) return -1;
+    my_to_fp12(&f, &e);
+    hard_part(&f, &f);
+    memcpy(out, &f, 576);
+    return 0;
+}
+int orc_easy_part(const uint64_t* in, uint64_t* out) {
+    fp12 a, f; myfp12 m, e;
+    memcpy(&a, in, 576); my_from_fp12(&m, &a);
+    if (easy_part(&e, &m)) return -1;
+    my_to_fp12(&f, &e); memcpy(out, &f, 576);
+    return 0;
+}
+void orc_hard_part(const uint64_t* in, uint64_t* out) { fp12 a, f; memcpy(&a, in, 576); hard_part(&f, &a); memcpy(out, &f, 576); }
+
+/* native_pairing per independent pair (pairing.rs:8-13) */
+int orc_pairing_batch(const uint64_t* g1, const uint64_t* g2, const uint8_t* flags, size_t n, uint64_t* out, int with_final_exp) {
+    int rc = 0;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (long i = 0; i < (long)n; i++) {
+        uint64_t f[72];
+        orc_multi_miller_loop(g1 + i * 12, g2 + i * 24, flags ? flags + i : NULL, 1, f);
+        if (with_final_exp) { if (orc_final_exponentiation(f, out + i * 72)) rc = -1; }
+        else memcpy(out + i * 72, f, 576);
+    }
+    return rc;
+}
+int orc_final_exp_batch(const uint64_t* in, size_t n, uint64_t* out) {
+    int rc = 0;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (long i = 0; i < (long)n; i++) if (orc_final_exponentiation(in + i * 72, out + i * 72)) rc = -1;
+    return rc;
+}
+void orc_g2_prepare(const uint64_t* g2, uint64_t* out /* 68*36 u64 */) {
+    fp2 qx, qy; ellcoeff c[68];
+    fp_set(&qx.c0, g2); fp_set(&qx.c1, g2 + 6); fp_set(&qy.c0, g2 + 12); fp_set(&qy.c1, g2 + 18);
+    g2_prepare(c, &qx, &qy);
+    memcpy(out, c, sizeof c);
+}
+void orc_ell(const uint64_t* f_in, const uint64_t* coeff, const uint64_t* g1, uint64_t* f_out) {
+    fp12 f; ellcoeff c; fp px, py;
+    memcpy(&f, f_in, 576); memcpy(&c, coeff, 288); fp_set(&px, g1); fp_set(&py, g1 + 6);
+    ell(&f, &c, &px, &py);
+    memcpy(f_out, &f, 576);
+}
+void orc_fq12_mul(const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    fp12 x, y; myfp12 mx, my, mo; memcpy(&x, a, 576); memcpy(&y, b, 576);
+    my_from_fp12(&mx, &x); my_from_fp12(&my, &y); my_mul(&mo, &mx, &my); my_to_fp12(&x, &mo); memcpy(out, &x, 576);
+}
+void orc_frobenius(const uint64_t* a, int power, uint64_t* out) { fp12 x, y; memcpy(&x, a, 576); frob_fp12(&y, &x, power); memcpy(out, &y, 576); }
+int orc_fq12_inverse(const uint64_t* a, uint64_t* out) { fp12 x, y; memcpy(&x, a, 576); if (fp12_inv(&y, &x)) return -1; memcpy(out, &y, 576); return 0; }
+/* canonical <-> Montgomery */
+void orc_to_mont(const uint64_t* a, uint64_t* out) { fp x, r2, y; fp_set(&x, a); fp_set(&r2, ORC_R2); fp_mul(&y, &x, &r2); memcpy(out, y.l, 48); }
+void orc_from_mont(const uint64_t* a, uint64_t* out) { fp x, one, y; fp_set(&x, a); memset(&one, 0, sizeof one); one.l[0] = 1; fp_mul(&y, &x, &one); memcpy(out, y.l, 48); }
+/* scalar multiplication for synthetic inputs is done in Python for small n; for large batches the
+ * benchmark tiles a small set of distinct pairs. */
+#ifdef _OPENMP
+#include <omp.h>
+void orc_set_threads(int n) { omp_set_num_threads(n); }
+int orc_get_max_threads(void) { return omp_get_max_threads(); }
+#else
+void orc_set_threads(int n) { (void)n; }
+int orc_get_max_threads(void) { return 1; }
+#endif

@@ -121,8 +121,8 @@ struct bls381_ctx {
     uint4* d_consts = nullptr;
     uint4* d_kp = nullptr;
     DevBuf user_in, user_in2, user_in3, user_out, flags, bufA, bufB, bufC, bufTmp, zflags;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    float last_ms[3] = {0, 0, 0};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float last_ms[4] = {0, 0, 0, 0};  // Miller kernel, fe1 + inversion, fe2 kernel, whole device call
     std::mutex mu;
     // witness machinery (built lazily)
     WitnessDevice wit;
@@ -202,9 +202,9 @@ extern "C" void bls381_ctx_destroy(bls381_ctx* c) {
 static inline int pad_elems(size_t n) { return (int)((n + 63) / 64 * 64); }
 static inline size_t soa_bytes(int slots, int npad) { return (size_t)slots * 48 * npad; }
 
-template <int K>
-static hipError_t launch_vm_k(bls381_ctx* c, const DevProgram& p, const uint4* gin, uint4* gout, uint4* gtmp, int n,
-                              int npad) {
+template <int K, int TAG>
+static hipError_t launch_vm_kt(bls381_ctx* c, const DevProgram& p, const uint4* gin, uint4* gout, uint4* gtmp, int n,
+                               int npad) {
     constexpr int GPW = 4 * (64 / K);
     VmArgs a;
     a.hdrs = p.d_hdrs; a.descs = p.d_descs; a.nsteps = (int)p.host.hdrs.size(); a.lds_slots = p.host.n_lds_slots;
@@ -212,13 +212,20 @@ static hipError_t launch_vm_k(bls381_ctx* c, const DevProgram& p, const uint4* g
     size_t lds = (size_t)p.host.n_lds_slots * 48 * GPW + KP_ROWS * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)vm_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)vm_kernel<K, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     int blocks = (n + GPW - 1) / GPW;
-    hipLaunchKernelGGL(vm_kernel<K>, dim3(blocks), dim3(VM_THREADS), lds, c->stream, a);
+    hipLaunchKernelGGL((vm_kernel<K, TAG>), dim3(blocks), dim3(VM_THREADS), lds, c->stream, a);
     return hipGetLastError();
+}
+template <int K>
+static hipError_t launch_vm_k(bls381_ctx* c, const DevProgram& p, const uint4* gin, uint4* gout, uint4* gtmp, int n,
+                              int npad) {
+    if (p.host.name == "miller") return launch_vm_kt<K, TAG_MILLER>(c, p, gin, gout, gtmp, n, npad);
+    if (p.host.name == "fe2") return launch_vm_kt<K, TAG_FINAL_EXP>(c, p, gin, gout, gtmp, n, npad);
+    return launch_vm_kt<K, TAG_AUX>(c, p, gin, gout, gtmp, n, npad);
 }
 
 static int run_program(bls381_ctx* c, const char* which, const void* gin, void* gout, int n, int npad) {
@@ -258,6 +265,7 @@ static int unpack(bls381_ctx* c, const void* soa, void* aos_dev, int n, int npad
 enum { CHUNK = 1 << 16 };
 
 // final exponentiation of `n` Fq12 sitting in slots 0..11 of `fin` (SoA); result to slots 0..11 of `fout`.
+// Records ev[3] between the inversion and the second program.
 static int final_exp_soa(bls381_ctx* c, const void* fin, void* fout, int n, int npad, uint8_t* zero_dev,
                          const char* part2 = "fe2") {
     HIPCHK(c->bufC.ensure(soa_bytes(FE_CARRY, npad)));
@@ -266,6 +274,7 @@ static int final_exp_soa(bls381_ctx* c, const void* fin, void* fout, int n, int 
     hipLaunchKernelGGL(fp_inverse_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, (uint4*)c->bufC.p, 0, n, npad,
                        c->d_consts, zero_dev);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[3], c->stream));
     return run_program(c, part2, c->bufC.p, fout, n, npad);
 }
 
@@ -294,16 +303,20 @@ static int miller_dev_locked(bls381_ctx* c, const uint64_t* g1, const uint64_t* 
         if (with_final_exp) {
             rc = final_exp_soa(c, c->bufB.p, c->bufB.p, m, npad, nullptr);
             if (rc) return rc;
+        } else {
+            HIPCHK(hipEventRecord(c->ev[3], c->stream));
         }
-        HIPCHK(hipEventRecord(c->ev[3], c->stream));
+        HIPCHK(hipEventRecord(c->ev[4], c->stream));
         rc = unpack(c, c->bufB.p, out + off * 72, m, npad, 12, 0);
         if (rc) return rc;
+        HIPCHK(hipEventRecord(c->ev[5], c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (n) {
+    if (n) {  // timings of the last chunk
         (void)hipEventElapsedTime(&c->last_ms[0], c->ev[1], c->ev[2]);
         (void)hipEventElapsedTime(&c->last_ms[1], c->ev[2], c->ev[3]);
-        (void)hipEventElapsedTime(&c->last_ms[2], c->ev[0], c->ev[3]);
+        (void)hipEventElapsedTime(&c->last_ms[2], c->ev[3], c->ev[4]);
+        (void)hipEventElapsedTime(&c->last_ms[3], c->ev[0], c->ev[5]);
     }
     return 0;
 }
@@ -365,15 +378,17 @@ static int final_exp_dev_locked(bls381_ctx* c, const uint64_t* in, size_t n, uin
         HIPCHK(hipEventRecord(c->ev[2], c->stream));
         rc = final_exp_soa(c, c->bufA.p, c->bufB.p, m, npad, zero_dev ? zero_dev + off : nullptr, part2);
         if (rc) return rc;
-        HIPCHK(hipEventRecord(c->ev[3], c->stream));
+        HIPCHK(hipEventRecord(c->ev[4], c->stream));
         rc = unpack(c, c->bufB.p, out + off * 72, m, npad, 12, 0);
         if (rc) return rc;
+        HIPCHK(hipEventRecord(c->ev[5], c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     if (n) {
         c->last_ms[0] = 0;
         (void)hipEventElapsedTime(&c->last_ms[1], c->ev[2], c->ev[3]);
-        (void)hipEventElapsedTime(&c->last_ms[2], c->ev[0], c->ev[3]);
+        (void)hipEventElapsedTime(&c->last_ms[2], c->ev[3], c->ev[4]);
+        (void)hipEventElapsedTime(&c->last_ms[3], c->ev[0], c->ev[5]);
     }
     return 0;
 }
@@ -688,10 +703,10 @@ extern "C" int bls381_debug_constants(uint32_t* out, size_t capacity_fp) {
     std::memcpy(out, c.data(), c.size() * 4);
     return 0;
 }
-extern "C" int bls381_last_timing(bls381_ctx* c, float ms[3]) {
+extern "C" int bls381_last_timing(bls381_ctx* c, float ms[4]) {
     if (!c || !ms) return fail(BLS381_ERR_INVALID, "NULL argument");
     std::lock_guard<std::mutex> lock_(c->mu);
-    ms[0] = c->last_ms[0]; ms[1] = c->last_ms[1]; ms[2] = c->last_ms[2];
+    for (int i = 0; i < 4; i++) ms[i] = c->last_ms[i];
     return 0;
 }
 
@@ -702,8 +717,8 @@ __global__ void mac_rate_kernel(u32* out, u32 seed, int iters) {
     for (int i = 0; i < 8; i++) acc[i] = i + seed;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) acc[i] = (u64)a * b + acc[i];
-        a += (u32)acc[0];
+        for (int i = 0; i < 8; i++)
+            asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b) : "vcc");
     }
     u64 s = 0;
     for (int i = 0; i < 8; i++) s += acc[i];

@@ -32,7 +32,11 @@ __device__ __forceinline__ void unpack3(const uint4& a, const uint4& b, const ui
     x[8] = c.x; x[9] = c.y; x[10] = c.z; x[11] = c.w;
 }
 
-template <int K>
+// TAG only gives the Miller-loop, final-exponentiation and auxiliary launches distinct kernel
+// names in profiler output; the code is identical.
+enum { TAG_MILLER = 0, TAG_FINAL_EXP = 1, TAG_AUX = 2 };
+
+template <int K, int TAG>
 __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
     constexpr int G = 64 / K;      // groups per wave
     constexpr int GPW = 4 * G;     // groups per workgroup

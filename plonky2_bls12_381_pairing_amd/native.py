@@ -194,7 +194,7 @@ class Context:
 
     # ---- measurement
     def last_timing(self):
-        ms = (C.c_float * 3)()
+        ms = (C.c_float * 4)()
         check(lib.bls381_last_timing(self._h, ms))
         return list(ms)
 

@@ -1,0 +1,231 @@
+"""Parity of the HIP path with the oracle, through the C ABI, on a real MI355X.
+Integer work: every comparison is bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import bls381_ref as R
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pairing_vectors.json")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import plonky2_bls12_381_pairing_amd as B
+    c = B.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def CO():
+    import c_oracle
+    return c_oracle
+
+
+def _fq12(hexes):
+    return R.fq12_from_flat_ark([int(h, 16) for h in hexes])
+
+
+def test_golden_vectors(ctx):
+    g = json.load(open(GOLDEN))
+    ps = [(int(c["g1"][0], 16), int(c["g1"][1], 16)) for c in g["cases"]]
+    qs = [((int(c["g2"][0], 16), int(c["g2"][1], 16)), (int(c["g2"][2], 16), int(c["g2"][3], 16))) for c in g["cases"]]
+    ml = ctx.miller_loop_batch(H.g1_array(ps), H.g2_array(qs))
+    pr = ctx.pairing_batch(H.g1_array(ps), H.g2_array(qs))
+    for i, c in enumerate(g["cases"]):
+        assert H.fq12_from_row(ml[i]) == _fq12(c["miller"])
+        assert H.fq12_from_row(pr[i]) == _fq12(c["pairing"])
+    assert "%096x" % R.fq12_flatten_ark(H.fq12_from_row(pr[0]))[0] == g["gt_generator_c000"]
+    fe = g["final_exp"]
+    x = H.fq12_array([_fq12(fe["x"])])
+    assert H.fq12_from_row(ctx.final_exponentiation_batch(x)[0]) == _fq12(fe["final_exp"])
+    assert H.fq12_from_row(ctx.easy_part_batch(x)[0]) == _fq12(fe["easy"])
+    assert H.fq12_from_row(ctx.hard_part_batch(x)[0]) == _fq12(fe["hard"])
+    assert H.fq12_from_row(ctx.frobenius_map_batch(x, 1)[0]) == _fq12(fe["frob1"])
+    assert H.fq12_from_row(ctx.frobenius_map_batch(x, 2)[0]) == _fq12(fe["frob2"])
+
+
+@pytest.mark.parametrize("n", [1, 7, 33, 257])
+def test_pairing_ragged_sizes_vs_python_oracle(ctx, n):
+    ps, qs = H.random_pairs(min(n, 9), 1000 + n)
+    ps, qs = (ps * (n // len(ps) + 1))[:n], (qs * (n // len(qs) + 1))[:n]
+    qs = qs[1:] + qs[:1]                                  # pair P_i with a different Q
+    out = ctx.pairing_batch(H.g1_array(ps), H.g2_array(qs))
+    cache = {}
+    for i in range(n):
+        key = (ps[i], qs[i])
+        if key not in cache:
+            cache[key] = R.native_pairing([ps[i]], [qs[i]])
+        assert H.fq12_from_row(out[i]) == cache[key]
+
+
+def test_empty_batches(ctx):
+    z1, z2 = np.zeros((0, 12), np.uint64), np.zeros((0, 24), np.uint64)
+    assert ctx.pairing_batch(z1, z2).shape == (0, 72)
+    assert ctx.miller_loop_batch(z1, z2).shape == (0, 72)
+    assert ctx.final_exponentiation_batch(np.zeros((0, 72), np.uint64)).shape == (0, 72)
+    out = ctx.multi_miller_loop_native(z1, z2)            # empty product
+    assert H.fq12_from_row(out) == R.FQ12_ONE
+
+
+def test_infinity_pairs_and_length_mismatch(ctx):
+    ps, qs = H.random_pairs(6, 5)
+    ps[0] = None
+    qs[3] = None
+    ps[5] = None
+    qs[5] = None
+    fl = H.inf_flags(ps, qs)
+    ml = ctx.miller_loop_batch(H.g1_array(ps), H.g2_array(qs), fl)
+    pr = ctx.pairing_batch(H.g1_array(ps), H.g2_array(qs), fl)
+    for i in range(6):
+        assert H.fq12_from_row(ml[i]) == R.multi_miller_loop([ps[i]], [qs[i]])
+        assert H.fq12_from_row(pr[i]) == R.native_pairing([ps[i]], [qs[i]])
+    assert H.fq12_from_row(pr[0]) == R.FQ12_ONE
+    with pytest.raises(ValueError):                        # zip_eq panics in the reference
+        ctx.pairing_batch(H.g1_array(ps), H.g2_array(qs[:-1]))
+
+
+def test_final_exponentiation_arbitrary_input_and_zero(ctx):
+    import plonky2_bls12_381_pairing_amd as B
+    xs = H.random_fq12(5, 77)                             # not in the cyclotomic subgroup
+    out = ctx.final_exponentiation_batch(H.fq12_array(xs))
+    for i, x in enumerate(xs):
+        assert H.fq12_from_row(out[i]) == R.final_exponentiation(x)
+    easy = ctx.easy_part_batch(H.fq12_array(xs[:2]))
+    hard = ctx.hard_part_batch(H.fq12_array(xs[:2]))
+    for i in range(2):
+        assert H.fq12_from_row(easy[i]) == R.myfq12_to_fq12(R.easy_part_native(R.myfq12_from_fq12(xs[i])))
+        assert H.fq12_from_row(hard[i]) == R.hard_part_native(xs[i])
+    bad = H.fq12_array([xs[0], R.FQ12_ZERO])
+    with pytest.raises(B.Bls381Error) as ei:               # the reference panics on division by zero
+        ctx.final_exponentiation_batch(bad)
+    assert ei.value.code == -4
+
+
+def test_tower_helpers(ctx):
+    a, b = H.random_fq12(3, 8), H.random_fq12(3, 9)
+    out = ctx.fq12_mul_batch(H.fq12_array(a), H.fq12_array(b))
+    for i in range(3):
+        assert H.fq12_from_row(out[i]) == R.fq12_mul(a[i], b[i])
+        assert R.myfq12_from_fq12(H.fq12_from_row(out[i])) == R.myfq12_mul(R.myfq12_from_fq12(a[i]), R.myfq12_from_fq12(b[i]))
+    for pw in (1, 2):
+        fr = ctx.frobenius_map_batch(H.fq12_array(a), pw)
+        for i in range(3):
+            assert H.fq12_from_row(fr[i]) == R.myfq12_to_fq12(R.frobenius_map_native(R.myfq12_from_fq12(a[i]), pw))
+
+
+def test_g2_prepare_and_ell(ctx):
+    ps, qs = H.random_pairs(3, 31)
+    cf = ctx.g2_prepare_batch(H.g2_array(qs))
+    assert cf.shape == (3, 68, 3, 2, 6)
+    for i in range(3):
+        ref = R.g2_prepare(qs[i])
+        for k in range(68):
+            for j in range(3):
+                assert (H.u64_to_fq(cf[i, k, j, 0]), H.u64_to_fq(cf[i, k, j, 1])) == ref[k][j]
+    f = H.random_fq12(3, 32)
+    coeffs = np.ascontiguousarray(cf[:, 5].reshape(3, 36))
+    out = ctx.ell_batch(H.fq12_array(f), coeffs, H.g1_array(ps))
+    for i in range(3):
+        assert H.fq12_from_row(out[i]) == R.ell(f[i], R.g2_prepare(qs[i])[5], ps[i])
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 13])
+def test_multi_miller_loop_and_multi_pairing(ctx, n):
+    ps, qs = H.random_pairs(n, 200 + n)
+    fl = None
+    if n == 5:
+        ps[2] = None
+        fl = H.inf_flags(ps, qs)
+    got = ctx.multi_miller_loop_native(H.g1_array(ps), H.g2_array(qs), fl)
+    assert H.fq12_from_row(got) == R.multi_miller_loop(ps, qs)
+    e, is_one = ctx.native_pairing(H.g1_array(ps), H.g2_array(qs), fl)
+    assert H.fq12_from_row(e) == R.native_pairing(ps, qs)
+    assert not is_one
+
+
+def test_aggregate_signature_check_512_keys(ctx, CO):
+    """sum_i e(pk_i, H_i) * e(-G1, sigma) = 1 with sigma = sum sk_i H_i (a 512-key sync committee)."""
+    import random
+    rng = random.Random(512)
+    n = 512
+    base = 8                                              # distinct keys/messages, tiled to 512
+    sks = [rng.randrange(1, R.R_ORDER) for _ in range(base)]
+    hs = [rng.randrange(1, R.R_ORDER) for _ in range(base)]
+    pks = [R.g1_mul(R.G1_GEN, s) for s in sks]
+    Hs = [R.g2_mul(R.G2_GEN, h) for h in hs]
+    ps = [pks[i % base] for i in range(n)]
+    qs = [Hs[i % base] for i in range(n)]
+    sigma_scalar = sum(sks[i % base] * hs[i % base] for i in range(n)) % R.R_ORDER
+    sigma = R.g2_mul(R.G2_GEN, sigma_scalar)
+    ps.append(R.g1_neg(R.G1_GEN))
+    qs.append(sigma)
+    g1, g2 = H.g1_array(ps), H.g2_array(qs)
+    e, is_one = ctx.native_pairing(g1, g2)
+    assert is_one and H.fq12_from_row(e) == R.FQ12_ONE
+    ml = ctx.multi_miller_loop_native(g1, g2)
+    assert np.array_equal(ml, CO.multi_miller_loop(g1, g2))          # bit-for-bit vs the C oracle
+    # negative case: one wrong signature share
+    qs[-1] = R.g2_mul(R.G2_GEN, (sigma_scalar + 1) % R.R_ORDER)
+    e, is_one = ctx.native_pairing(g1, H.g2_array(qs))
+    assert not is_one
+    # the multi-GPU finishing step on gathered partial products
+    parts = np.stack([ctx.multi_miller_loop_native(g1[i::4], g2[i::4]) for i in range(4)])
+    e2, one2 = ctx.finish_multi_pairing(parts)
+    assert one2 and H.fq12_from_row(e2) == R.FQ12_ONE
+
+
+def test_fq12_inverse_generator_limbs(ctx):
+    import plonky2_bls12_381_pairing_amd as B
+    xs = H.random_fq12(4, 55)
+    lim = np.zeros((4, 144), np.uint32)
+    for i, x in enumerate(xs):
+        lim[i] = [l for c in R.myfq12_from_fq12(x) for l in R.fq_to_u32_limbs(c)]
+    inv = ctx.fq12_inverse_limbs_batch(lim)
+    for i, x in enumerate(xs):
+        want = R.myfq12_from_fq12(R.fq12_inv(x))
+        got = [R.u32_limbs_to_int(inv[i, 12 * k:12 * k + 12]) for k in range(12)]
+        assert got == want
+    bad = lim.copy()
+    bad[1] = 0                                            # zero: inverse().unwrap() panics
+    with pytest.raises(B.Bls381Error):
+        ctx.fq12_inverse_limbs_batch(bad)
+    bad = lim.copy()
+    bad[2, :12] = R.fq_to_u32_limbs(R.P)                  # >= p: from_biguint_to_fq panics
+    with pytest.raises(B.Bls381Error):
+        ctx.fq12_inverse_limbs_batch(bad)
+
+
+def test_full_batch_65536_against_c_oracle_and_bilinearity(ctx, CO):
+    """BASELINE config 2: 65,536 independent pairings, every output compared with the CPU oracle
+    on the distinct inputs, plus size-independent properties on the whole batch."""
+    n = 65536
+    base = 64
+    ps, qs = H.random_pairs(base, 4242)
+    g1b, g2b = H.g1_array(ps), H.g2_array(qs)
+    idx_p = np.arange(n) % base
+    idx_q = (np.arange(n) * 7 + np.arange(n) // base) % base
+    g1, g2 = g1b[idx_p], g2b[idx_q]
+    out = ctx.pairing_batch(g1, g2)
+    # distinct (p, q) combinations, each checked once against the C oracle
+    combos = {}
+    for i in range(n):
+        combos.setdefault((int(idx_p[i]), int(idx_q[i])), i)
+    keys = list(combos.keys())
+    ref = CO.pairing_batch(g1b[[k[0] for k in keys]], g2b[[k[1] for k in keys]])
+    ref_of = {k: ref[j] for j, k in enumerate(keys)}
+    for i in range(n):
+        assert np.array_equal(out[i], ref_of[(int(idx_p[i]), int(idx_q[i]))]), i
+    # e(P, Q) * e(P, -Q) = 1 through the same kernels (multiplication on the GPU as well)
+    m = 1024
+    g2n = H.g2_array([R.g2_neg(q) for q in qs])[idx_q[:m]]
+    neg = ctx.pairing_batch(g1[:m], g2n)
+    prod = ctx.fq12_mul_batch(out[:m], neg)
+    one = H.fq12_array([R.FQ12_ONE])[0]
+    assert all(np.array_equal(prod[i], one) for i in range(m))

@@ -1,0 +1,100 @@
+"""Host logic without a GPU: the C-ABI library loads and exports every declared symbol, the
+scheduler's step programs compute the oracle's values in a big-integer interpreter, and the
+product path fails loudly when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import bls381_ref as R
+import helpers as H
+import vm_sim as S
+from plonky2_bls12_381_pairing_amd import _lib
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+M, F = R.to_mont, R.from_mont
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "bls381_hip.h")).read()
+    declared = set(re.findall(r"\b(bls381_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("bls381_ctx")
+    assert declared == set(_lib.EXPORTED)
+    for name in declared:
+        assert hasattr(_lib.lib, name), name
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_no_cpu_fallback():
+    if _has_gpu():
+        pytest.skip("a GPU is present")
+    ctx = C.c_void_p()
+    rc = _lib.lib.bls381_ctx_create(C.byref(ctx), 0)
+    assert rc == -2 and not ctx.value                      # BLS381_ERR_NO_DEVICE, no context
+    assert b"no HIP device" in _lib.lib.bls381_last_error()
+    import plonky2_bls12_381_pairing_amd as B
+    with pytest.raises(B.Bls381Error):
+        B.Context(0)
+
+
+def test_constant_table():
+    c = S.get_constants()
+    assert F(c[0]) == 1 and F(c[1]) == R.TWO_INV and c[18] == 1 and c[17] == M(R.MONT_R)
+    g1, g2 = R.frob_coeffs(1), R.frob_coeffs(2)
+    for i in range(1, 6):
+        assert (F(c[2 + 2 * (i - 1)]), F(c[3 + 2 * (i - 1)])) == R.fq2_pow(g1, i)
+        assert F(c[12 + i - 1]) == R.fq2_pow(g2, i)[0]
+
+
+@pytest.mark.parametrize("K,slots", [(8, 0), (6, 40), (9, 0), (12, 0), (16, 0)])
+def test_miller_and_final_exp_programs(K, slots):
+    ps, qs = H.random_pairs(1, 100 + K)
+    p, q = ps[0], qs[0]
+    prog = S.get_program("miller", K, slots)
+    assert prog["n_in"] == 6 and prog["n_out"] == 12
+    out = S.run_program(prog, [M(p[0]), M(p[1]), M(q[0][0]), M(q[0][1]), M(q[1][0]), M(q[1][1])])
+    ml = R.fq12_from_flat_ark([F(x) for x in out])
+    assert ml == R.multi_miller_loop([p], [q])
+    mid = S.run_program(S.get_program("fe1", K, slots), [M(x) for x in R.fq12_flatten_ark(ml)])
+    mid[0] = M(R.fq_inv(F(mid[0])))                       # the Fp inversion kernel's job
+    out = S.run_program(S.get_program("fe2", K, slots), mid)
+    assert R.fq12_from_flat_ark([F(x) for x in out]) == R.native_pairing([p], [q])
+
+
+def test_auxiliary_programs():
+    a, b = H.random_fq12(2, 17)
+    fa, fb = R.fq12_flatten_ark(a), R.fq12_flatten_ark(b)
+    run = lambda name, gin: [F(x) for x in S.run_program(S.get_program(name), [M(v) for v in gin])]
+    assert R.fq12_from_flat_ark(run("fq12mul", fa + fb)) == R.fq12_mul(a, b)
+    assert R.fq12_from_flat_ark(run("hardgen", fa)) == R.hard_part_native(a)
+    for pw in (1, 2):
+        want = R.myfq12_to_fq12(R.frobenius_map_native(R.myfq12_from_fq12(a), pw))
+        assert R.fq12_from_flat_ark(run("frob%d" % pw, fa)) == want
+    p = R.g1_mul(R.G1_GEN, 5)
+    c = tuple((fb[2 * i], fb[2 * i + 1]) for i in range(3))
+    assert R.fq12_from_flat_ark(run("ell", fa + fb[:6] + [p[0], p[1]])) == R.ell(a, c, p)
+    q = R.g2_mul(R.G2_GEN, 77)
+    got = run("g2prep", [q[0][0], q[0][1], q[1][0], q[1][1]])
+    assert got == [x for cf in R.g2_prepare(q) for fq2 in cf for x in fq2]
+    # easy part through the split inverse
+    mid = S.run_program(S.get_program("fe1"), [M(v) for v in fa])
+    mid[0] = M(R.fq_inv(F(mid[0])))
+    out = [F(x) for x in S.run_program(S.get_program("easy2"), mid)]
+    assert R.fq12_from_flat_ark(out) == R.myfq12_to_fq12(R.easy_part_native(R.myfq12_from_fq12(a)))
+    # Fq12InverseGenerator on canonical MyFq12-ordered values (no Montgomery form at the boundary)
+    am = R.myfq12_from_fq12(a)
+    mid = S.run_program(S.get_program("inv1"), am)
+    mid[0] = M(R.fq_inv(F(mid[0])))
+    assert S.run_program(S.get_program("inv2"), mid) == R.myfq12_from_fq12(R.fq12_inv(a))
+
+
+def test_program_statistics():
+    p = S.get_program("miller", 8, 0)
+    # 63 doublings + 5 additions: the multiplication count must stay at or below the reference's model
+    assert 6000 < p["n_fmul"] <= 7141
+    assert S.get_program("fe2", 8, 0)["n_fmul"] <= 8119
