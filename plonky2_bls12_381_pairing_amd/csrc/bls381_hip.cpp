@@ -613,12 +613,43 @@ extern "C" int bls381_finish_multi_pairing(bls381_ctx* c, const uint64_t* partia
 }
 
 // ------------------------------------------------------------------ Fq12 inverse on witness limbs
+// x_dev -> inv_dev: n x 144 u32 canonical limbs in MyFq12 order, both in device memory.
+// zero_flags (host, may be NULL) receives 1 per item whose value is zero.
+static int inverse_limbs_dev_locked(bls381_ctx* c, const uint32_t* x_dev, size_t n, uint32_t* inv_dev,
+                                    uint8_t* zero_flags) {
+    bool any_zero = false;
+    for (size_t off = 0; off < n; off += CHUNK) {
+        int m = (int)std::min<size_t>(CHUNK, n - off);
+        int npad = pad_elems(m);
+        int rc;
+        HIPCHK(c->bufA.ensure(soa_bytes(12, npad)));
+        HIPCHK(c->bufB.ensure(soa_bytes(12, npad)));
+        HIPCHK(c->bufC.ensure(soa_bytes(FE_CARRY, npad)));
+        HIPCHK(c->zflags.ensure(m));
+        if ((rc = pack(c, x_dev + off * 144, c->bufA.p, m, npad, 12, 0))) return rc;
+        if ((rc = run_program(c, "inv1", c->bufA.p, c->bufC.p, m, npad))) return rc;
+        hipLaunchKernelGGL(fp_inverse_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, (uint4*)c->bufC.p, 0, m, npad,
+                           c->d_consts, (uint8_t*)c->zflags.p);
+        HIPCHK(hipGetLastError());
+        if ((rc = run_program(c, "inv2", c->bufC.p, c->bufB.p, m, npad))) return rc;
+        if ((rc = unpack(c, c->bufB.p, inv_dev + off * 144, m, npad, 12, 0))) return rc;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        std::vector<uint8_t> z(m);
+        HIPCHK(hipMemcpy(z.data(), c->zflags.p, m, hipMemcpyDeviceToHost));
+        for (int i = 0; i < m; i++) {
+            if (z[i]) any_zero = true;
+            if (zero_flags) zero_flags[off + i] = z[i];
+        }
+    }
+    return any_zero ? BLS381_ERR_ZERO : 0;
+}
+
 extern "C" int bls381_fq12_inverse_limbs_batch(bls381_ctx* c, const uint32_t* x, size_t n, uint32_t* inv, uint8_t* err) {
     CTX_GUARD(c);
     if (n == 0) return 0;
     if (!x || !inv) return fail(BLS381_ERR_INVALID, "NULL buffer");
     // range check on the host: from_biguint_to_fq (src/utils/helpers.rs:154-157) rejects values >= p
-    std::vector<uint8_t> e(n, 0);
+    std::vector<uint8_t> e(n, 0), z(n, 0);
     bool bad = false;
     for (size_t i = 0; i < n; i++)
         for (int k = 0; k < 12; k++) {
@@ -628,28 +659,12 @@ extern "C" int bls381_fq12_inverse_limbs_batch(bls381_ctx* c, const uint32_t* x,
             if (cmp >= 0) { e[i] = 1; bad = true; }
         }
     int rc;
-    for (size_t off = 0; off < n; off += CHUNK) {
-        int m = (int)std::min<size_t>(CHUNK, n - off);
-        int npad = pad_elems(m);
-        if ((rc = h2d(c, c->user_in, x + off * 144, (size_t)m * 576))) return rc;
-        HIPCHK(c->bufA.ensure(soa_bytes(12, npad)));
-        HIPCHK(c->bufB.ensure(soa_bytes(12, npad)));
-        HIPCHK(c->bufC.ensure(soa_bytes(FE_CARRY, npad)));
-        HIPCHK(c->zflags.ensure(m));
-        HIPCHK(c->user_out.ensure((size_t)m * 576));
-        if ((rc = pack(c, c->user_in.p, c->bufA.p, m, npad, 12, 0))) return rc;
-        if ((rc = run_program(c, "inv1", c->bufA.p, c->bufC.p, m, npad))) return rc;
-        hipLaunchKernelGGL(fp_inverse_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, (uint4*)c->bufC.p, 0, m, npad,
-                           c->d_consts, (uint8_t*)c->zflags.p);
-        HIPCHK(hipGetLastError());
-        if ((rc = run_program(c, "inv2", c->bufC.p, c->bufB.p, m, npad))) return rc;
-        if ((rc = unpack(c, c->bufB.p, c->user_out.p, m, npad, 12, 0))) return rc;
-        HIPCHK(hipStreamSynchronize(c->stream));
-        HIPCHK(hipMemcpy(inv + off * 144, c->user_out.p, (size_t)m * 576, hipMemcpyDeviceToHost));
-        std::vector<uint8_t> z(m);
-        HIPCHK(hipMemcpy(z.data(), c->zflags.p, m, hipMemcpyDeviceToHost));
-        for (int i = 0; i < m; i++) if (z[i] && !e[off + i]) { e[off + i] = 2; bad = true; }
-    }
+    if ((rc = h2d(c, c->user_in, x, n * 576))) return rc;
+    HIPCHK(c->user_out.ensure(n * 576));
+    rc = inverse_limbs_dev_locked(c, (const uint32_t*)c->user_in.p, n, (uint32_t*)c->user_out.p, z.data());
+    if (rc && rc != BLS381_ERR_ZERO) return rc;
+    HIPCHK(hipMemcpy(inv, c->user_out.p, n * 576, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) if (z[i] && !e[i]) { e[i] = 2; bad = true; }
     if (err) std::memcpy(err, e.data(), n);
     if (bad) return fail(BLS381_ERR_ZERO, "an input is zero or has a coefficient >= p");
     return 0;
@@ -669,8 +684,11 @@ extern "C" int bls381_pairing_witness_batch(bls381_ctx* c, const uint64_t* g1, c
     if (n == 0) return 0;
     if (!g1 || !g2 || !trace) return fail(BLS381_ERR_INVALID, "NULL buffer");
     std::string err;
-    int rc = c->wit.run(c->stream, (const uint4*)c->d_consts, g1, g2, n, trace, err);
-    if (rc) return fail(rc, err);
+    auto inv = [](void* cx, const uint32_t* x_dev, size_t m, uint32_t* inv_dev) -> int {
+        return inverse_limbs_dev_locked((bls381_ctx*)cx, x_dev, m, inv_dev, nullptr);
+    };
+    int rc = c->wit.run(c->stream, c, inv, g1, g2, n, trace, err);
+    if (rc) return fail(rc, err.empty() ? g_err : err);
     return 0;
 }
 

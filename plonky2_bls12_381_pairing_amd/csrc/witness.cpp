@@ -1,8 +1,541 @@
 #include "witness.h"
+
+#include <algorithm>
+#include <cstring>
+
+#include "bls381_constants.h"
+#include "fp_dev.h"
+
 namespace bls381 {
-const WitnessProgram& witness_program() { static WitnessProgram w; return w; }
-int WitnessDevice::run(hipStream_t, const uint4*, const uint64_t*, const uint64_t*, size_t, uint32_t*, std::string& err) {
-    err = "witness trace not built yet"; return -1;
+
+// ================================================================= host: symbolic replay
+namespace {
+
+struct WB {  // builder: every method appends one row
+    std::vector<uint8_t> kinds;
+    std::vector<uint32_t> ra, rb;
+    uint32_t emit(WitnessKind k, uint32_t a, uint32_t b) {
+        kinds.push_back(k); ra.push_back(a); rb.push_back(b);
+        return (uint32_t)kinds.size() - 1;  // WREF_ROW space
+    }
+    // FqTarget ops, /root/reference/src/fields/fq_target.rs:144-187
+    uint32_t add(uint32_t a, uint32_t b) { return emit(WK_ADD, a, b); }
+    uint32_t sub(uint32_t a, uint32_t b) { return emit(WK_SUB, a, b); }
+    uint32_t mul(uint32_t a, uint32_t b) { return emit(WK_MUL, a, b); }
+    uint32_t neg(uint32_t a) { return emit(WK_NEG, a, a); }
+};
+inline uint32_t cst(int id) { return WREF_CONST | (uint32_t)id; }
+inline uint32_t inp(int id) { return WREF_INPUT | (uint32_t)id; }
+
+struct F2 { uint32_t c[2]; };
+struct F6 { uint32_t c[6]; };    // MyFq6 order  [c00,c10,c20,c01,c11,c21]
+struct F12 { uint32_t c[12]; };  // MyFq12 order
+
+// ---- Fq2Target, /root/reference/src/fields/fq2_target.rs
+F2 add(WB& w, F2 a, F2 b) { return {{w.add(a.c[0], b.c[0]), w.add(a.c[1], b.c[1])}}; }      // :94-104
+F2 sub(WB& w, F2 a, F2 b) { return {{w.sub(a.c[0], b.c[0]), w.sub(a.c[1], b.c[1])}}; }      // :117-127
+F2 neg(WB& w, F2 a) { return {{w.neg(a.c[0]), w.neg(a.c[1])}}; }                            // :106-115
+F2 mul(WB& w, F2 a, F2 b) {                                                                 // :145-163
+    uint32_t a0b0 = w.mul(a.c[0], b.c[0]);
+    uint32_t a1b1 = w.mul(a.c[1], b.c[1]);
+    uint32_t c0 = w.sub(a0b0, a1b1);
+    uint32_t a0b1 = w.mul(a.c[0], b.c[1]);
+    uint32_t a1b0 = w.mul(a.c[1], b.c[0]);
+    uint32_t c1 = w.add(a0b1, a1b0);
+    return {{c0, c1}};
 }
-void WitnessDevice::release() {}
+F2 simple_square(WB& w, F2 a) { return mul(w, a, a); }                                      // :218-220
+F2 dbl(WB& w, F2 a) { return add(w, a, a); }                                                // :222-224
+F2 mul_assign_by_fp(WB& w, F2 a, uint32_t s) { return {{w.mul(a.c[0], s), w.mul(a.c[1], s)}}; }  // :226-234
+F2 mul_by_nonresidue(WB& w, F2 a) { return {{w.sub(a.c[0], a.c[1]), w.add(a.c[0], a.c[1])}}; }   // :236-248
+F2 conjugate(WB& w, F2 a) { return {{a.c[0], w.neg(a.c[1])}}; }                             // :250-256
+
+// ---- Fq6Target, /root/reference/src/fields/fq6_target.rs
+F6 add(WB& w, F6 a, F6 b) { F6 r; for (int i = 0; i < 6; i++) r.c[i] = w.add(a.c[i], b.c[i]); return r; }  // :96-106
+F6 sub(WB& w, F6 a, F6 b) { F6 r; for (int i = 0; i < 6; i++) r.c[i] = w.sub(a.c[i], b.c[i]); return r; }  // :119-129
+inline void split(F6 s, F2& s0, F2& s1, F2& s2) { s0 = {{s.c[0], s.c[3]}}; s1 = {{s.c[1], s.c[4]}}; s2 = {{s.c[2], s.c[5]}}; }
+inline F6 join(F2 t1, F2 t2, F2 t3) { return {{t1.c[0], t2.c[0], t3.c[0], t1.c[1], t2.c[1], t3.c[1]}}; }
+F6 mul_by_01(WB& w, F6 s, F2 c0, F2 c1) {                                                   // :198-239
+    F2 s0, s1, s2; split(s, s0, s1, s2);
+    F2 a_a = mul(w, s0, c0);
+    F2 b_b = mul(w, s1, c1);
+    F2 t1 = mul(w, s2, c1);
+    t1 = mul_by_nonresidue(w, t1);
+    t1 = add(w, t1, a_a);
+    F2 c0c1 = add(w, c0, c1);
+    F2 s0s1 = add(w, s0, s1);
+    F2 t2 = mul(w, c0c1, s0s1);
+    t2 = sub(w, t2, a_a);
+    t2 = sub(w, t2, b_b);
+    F2 t3 = mul(w, s2, c0);
+    t3 = add(w, t3, b_b);
+    return join(t1, t2, t3);
 }
+F6 mul_by_1(WB& w, F6 s, F2 c1) {                                                           // :241-279
+    F2 s0, s1, s2; split(s, s0, s1, s2);
+    F2 b_b = mul(w, s1, c1);
+    F2 tmp = add(w, s1, s2);
+    F2 t1 = mul(w, c1, tmp);
+    t1 = sub(w, t1, b_b);
+    t1 = mul_by_nonresidue(w, t1);
+    tmp = add(w, s0, s1);
+    F2 t2 = mul(w, c1, tmp);
+    t2 = sub(w, t2, b_b);
+    return join(t1, t2, b_b);
+}
+F6 mul_by_nonresidue(WB& w, F6 s) {                                                         // :282-311
+    F2 s0, s1, s2; split(s, s0, s1, s2);
+    F2 c0 = mul_by_nonresidue(w, s2);
+    return join(c0, s0, s1);
+}
+
+// ---- Fq12Target, /root/reference/src/fields/fq12_target.rs
+F12 mul(WB& w, const F12& a, const F12& b) {                                                // :118-188
+    std::vector<uint32_t> a0b0, a0b1, a1b0, a1b1;
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+            uint32_t c00 = w.mul(a.c[i], b.c[j]);
+            uint32_t c01 = w.mul(a.c[i], b.c[j + 6]);
+            uint32_t c10 = w.mul(a.c[i + 6], b.c[j]);
+            uint32_t c11 = w.mul(a.c[i + 6], b.c[j + 6]);
+            if ((size_t)(i + j) < a0b0.size()) {
+                a0b0[i + j] = w.add(a0b0[i + j], c00);
+                a0b1[i + j] = w.add(a0b1[i + j], c01);
+                a1b0[i + j] = w.add(a1b0[i + j], c10);
+                a1b1[i + j] = w.add(a1b1[i + j], c11);
+            } else {
+                a0b0.push_back(c00); a0b1.push_back(c01); a1b0.push_back(c10); a1b1.push_back(c11);
+            }
+        }
+    uint32_t m[11], pl[11];
+    for (int i = 0; i < 11; i++) { m[i] = w.sub(a0b0[i], a1b1[i]); pl[i] = w.add(a0b1[i], a1b0[i]); }
+    F12 o;
+    for (int i = 0; i < 6; i++) {
+        if (i < 5) {
+            uint32_t term1 = w.mul(m[i + 6], cst(WC_ONE));
+            uint32_t term2 = w.neg(pl[i + 6]);
+            uint32_t s = w.add(m[i], term1);
+            o.c[i] = w.add(s, term2);
+        } else o.c[i] = m[i];
+    }
+    for (int i = 0; i < 6; i++) {
+        if (i < 5) {
+            uint32_t term2 = w.mul(pl[i + 6], cst(WC_ONE));
+            uint32_t s = w.add(pl[i], m[i + 6]);
+            o.c[i + 6] = w.add(s, term2);
+        } else o.c[i + 6] = pl[i];
+    }
+    return o;
+}
+inline void to_fq6(const F12& a, F6& c0, F6& c1) {                                          // :190-239
+    c0 = {{a.c[0], a.c[2], a.c[4], a.c[6], a.c[8], a.c[10]}};
+    c1 = {{a.c[1], a.c[3], a.c[5], a.c[7], a.c[9], a.c[11]}};
+}
+inline F12 from_fq6(F6 c0, F6 c1) {                                                         // :241-256
+    return {{c0.c[0], c1.c[0], c0.c[1], c1.c[1], c0.c[2], c1.c[2], c0.c[3], c1.c[3], c0.c[4], c1.c[4], c0.c[5], c1.c[5]}};
+}
+F12 mul_by_014(WB& w, const F12& f, F2 c0, F2 c1, F2 c4) {                                  // :258-295
+    F6 s0, s1; to_fq6(f, s0, s1);
+    F6 aa = mul_by_01(w, s0, c0, c1);
+    F6 bb = mul_by_1(w, s1, c4);
+    F2 o = add(w, c1, c4);
+    s1 = add(w, s1, s0);
+    s1 = mul_by_01(w, s1, c0, o);
+    s1 = sub(w, s1, aa);
+    s1 = sub(w, s1, bb);
+    s0 = mul_by_nonresidue(w, bb);
+    s0 = add(w, s0, aa);
+    return from_fq6(s0, s1);
+}
+F12 conjugate(WB& w, F12 a) {                                                               // :314-323
+    for (int k : {1, 3, 5, 7, 9, 11}) a.c[k] = w.neg(a.c[k]);
+    return a;
+}
+
+// ---- curves/g2.rs
+struct Proj { F2 x, y, z; };
+struct Coeff { F2 c0, c1, c2; };
+Coeff double_in_place(WB& w, Proj& r, uint32_t two_inv) {                                   // :59-98
+    F2 a = mul(w, r.x, r.y);
+    a = mul_assign_by_fp(w, a, two_inv);
+    F2 b = simple_square(w, r.y);
+    F2 c = simple_square(w, r.z);
+    F2 coeff_b = {{cst(WC_FOUR), cst(WC_FOUR)}};
+    F2 c_double = dbl(w, c);
+    c_double = add(w, c_double, c);
+    F2 e = mul(w, coeff_b, c_double);
+    F2 e_double = dbl(w, e);
+    F2 f = add(w, e_double, e);
+    F2 g = add(w, b, f);
+    g = mul_assign_by_fp(w, g, two_inv);
+    F2 y_add_z = add(w, r.y, r.z);
+    F2 y_z_squared = simple_square(w, y_add_z);
+    F2 b_add_c = add(w, b, c);
+    F2 h = sub(w, y_z_squared, b_add_c);
+    F2 i = sub(w, e, b);
+    F2 j = simple_square(w, r.x);
+    F2 e_square = simple_square(w, e);
+    F2 b_sub_f = sub(w, b, f);
+    F2 nx = mul(w, a, b_sub_f);
+    F2 g_square = simple_square(w, g);
+    F2 e_sq_double = dbl(w, e_square);
+    e_sq_double = add(w, e_sq_double, e_square);
+    F2 ny = sub(w, g_square, e_sq_double);
+    F2 nz = mul(w, b, h);
+    F2 j_double = dbl(w, j);
+    F2 j_triple = add(w, j_double, j);
+    r = Proj{nx, ny, nz};
+    return Coeff{i, j_triple, neg(w, h)};
+}
+Coeff add_in_place(WB& w, Proj& r, F2 qx, F2 qy) {                                          // :100-129
+    F2 qy_z = mul(w, qy, r.z);
+    F2 theta = sub(w, r.y, qy_z);
+    F2 qx_z = mul(w, qx, r.z);
+    F2 lambda = sub(w, r.x, qx_z);
+    F2 c = simple_square(w, theta);
+    F2 d = simple_square(w, lambda);
+    F2 e = mul(w, lambda, d);
+    F2 f = mul(w, r.z, c);
+    F2 g = mul(w, r.x, d);
+    F2 g_double = dbl(w, g);
+    F2 e_add_f = add(w, e, f);
+    F2 h = sub(w, e_add_f, g_double);
+    F2 nx = mul(w, lambda, h);
+    F2 g_sub_h = sub(w, g, h);
+    F2 e_mul_y = mul(w, e, r.y);
+    F2 theta_gh = mul(w, theta, g_sub_h);
+    F2 ny = sub(w, theta_gh, e_mul_y);
+    F2 nz = mul(w, r.z, e);
+    F2 lambda_qy = mul(w, lambda, qy);
+    F2 theta_qx = mul(w, theta, qx);
+    F2 j = sub(w, theta_qx, lambda_qy);
+    r = Proj{nx, ny, nz};
+    return Coeff{j, neg(w, theta), lambda};
+}
+
+const uint64_t BLSX = BLS381_X;
+
+// ---- final_exponentiation_helpers.rs
+F12 frobenius_map(WB& w, const F12& a, int power) {                                         // :14-57
+    F2 out[6];
+    for (int i = 0; i < 6; i++) {
+        F2 x = {{a.c[i], a.c[i + 6]}};
+        if (power % 2) x = conjugate(w, x);
+        if (i == 0) out[i] = x;  // frob_coeff == one
+        else {
+            int base = (power == 1 ? WC_FROB1_BASE : WC_FROB2_BASE) + 2 * (i - 1);
+            out[i] = mul(w, x, F2{{cst(base), cst(base + 1)}});
+        }
+    }
+    F12 o;
+    for (int i = 0; i < 6; i++) { o.c[i] = out[i].c[0]; o.c[i + 6] = out[i].c[1]; }
+    return o;
+}
+F12 pow_target(WB& w, const F12& a) {                                                       // :59-85
+    F12 res = a;
+    for (int i = 62; i >= 0; i--) {
+        res = mul(w, res, res);
+        if ((BLSX >> i) & 1) res = mul(w, res, a);
+    }
+    return res;
+}
+
+WitnessProgram build_program() {
+    WB w;
+    WitnessProgram P;
+    // G2PreparedTarget::from, curves/g2.rs:148-178
+    uint32_t two = w.add(cst(WC_ONE), cst(WC_ONE));
+    uint32_t two_inv = w.emit(WK_INV, two, two);
+    F2 qx = {{inp(2), inp(3)}}, qy = {{inp(4), inp(5)}};
+    Proj r{qx, qy, F2{{cst(WC_ONE), cst(WC_ZERO)}}};
+    std::vector<Coeff> coeffs;
+    for (int i = 62; i >= 0; i--) {
+        coeffs.push_back(double_in_place(w, r, two_inv));
+        if ((BLSX >> i) & 1) coeffs.push_back(add_in_place(w, r, qx, qy));
+    }
+    // multi_miller_loop, miller_loop.rs:19-61 (one pair; multiply_elements is the identity)
+    F12 f;
+    for (int k = 0; k < 12; k++) f.c[k] = cst(k == 0 ? WC_ONE : WC_ZERO);
+    size_t k = 0;
+    uint32_t px = inp(0), py = inp(1);
+    auto ell_target = [&](const Coeff& c) {                                                 // :63-79
+        F2 c2 = mul_assign_by_fp(w, c.c2, py);
+        F2 c1 = mul_assign_by_fp(w, c.c1, px);
+        f = mul_by_014(w, f, c.c0, c1, c2);
+    };
+    for (int i = 62; i >= 0; i--) {
+        f = mul(w, f, f);
+        ell_target(coeffs[k++]);
+        if ((BLSX >> i) & 1) ell_target(coeffs[k++]);
+    }
+    f = conjugate(w, f);
+    // final_exponentiation.rs:12-21 easy_part
+    F12 a = f;
+    F12 f1 = conjugate(w, a);
+    // Fq12Target::inv (fq12_target.rs:302-312): generator output, then x * inv connected to one
+    P.gen_start = w.kinds.size();
+    for (int i = 0; i < 12; i++) P.inv_input_refs[i] = a.c[i];
+    F12 inv;
+    for (int i = 0; i < 12; i++) inv.c[i] = w.emit(WK_GEN, 0, 0);
+    (void)mul(w, a, inv);
+    F12 f2 = mul(w, f1, inv);                                                               // div, :297-300
+    F12 f3 = frobenius_map(w, f2, 2);
+    F12 rr = mul(w, f3, f2);
+    // hard_part_target, final_exponentiation.rs:23-55
+    F12 y0 = mul(w, rr, rr);
+    F12 y1 = pow_target(w, rr);
+    y1 = conjugate(w, y1);
+    F12 y2 = conjugate(w, rr);
+    y1 = mul(w, y1, y2);
+    y2 = pow_target(w, y1);
+    y2 = conjugate(w, y2);
+    y1 = conjugate(w, y1);
+    y1 = mul(w, y1, y2);
+    y2 = pow_target(w, y1);
+    y2 = conjugate(w, y2);
+    y1 = frobenius_map(w, y1, 1);
+    y1 = mul(w, y1, y2);
+    F12 r2 = mul(w, rr, y0);
+    y0 = pow_target(w, y1);
+    y0 = conjugate(w, y0);
+    y2 = pow_target(w, y0);
+    y2 = conjugate(w, y2);
+    y0 = frobenius_map(w, y1, 2);
+    y1 = conjugate(w, y1);
+    y1 = mul(w, y1, y2);
+    y1 = mul(w, y1, y0);
+    (void)mul(w, r2, y1);
+
+    P.n_rows = w.kinds.size();
+    P.kinds = w.kinds;
+    for (uint8_t kd : w.kinds) P.counts[kd]++;
+    // level scheduling per phase
+    std::vector<uint32_t> level(P.n_rows, 0);
+    auto lvl = [&](uint32_t ref) -> uint32_t { return (ref >> 30) == 0 ? level[ref & WREF_MASK] + 1 : 0; };
+    for (int phase = 0; phase < 2; phase++) {
+        size_t lo = phase == 0 ? 0 : P.gen_start + 12, hi = phase == 0 ? P.gen_start : P.n_rows;
+        uint32_t maxl = 0;
+        for (size_t i = lo; i < hi; i++) {
+            uint32_t l = std::max(lvl(w.ra[i]), lvl(w.rb[i]));
+            // rows of the other phase (and generator rows) are complete before this phase starts
+            auto in_phase = [&](uint32_t ref) { return (ref >> 30) == 0 && (ref & WREF_MASK) >= lo && (ref & WREF_MASK) < hi; };
+            uint32_t la = in_phase(w.ra[i]) ? level[w.ra[i] & WREF_MASK] + 1 : 0;
+            uint32_t lb = in_phase(w.rb[i]) ? level[w.rb[i] & WREF_MASK] + 1 : 0;
+            l = std::max(la, lb);
+            level[i] = l;
+            maxl = std::max(maxl, l);
+        }
+        std::vector<std::vector<uint32_t>> by(maxl + 1);
+        for (size_t i = lo; i < hi; i++) by[level[i]].push_back((uint32_t)i);
+        P.level_start[phase].push_back(0);
+        for (auto& rows : by) {
+            for (uint32_t i : rows) P.ops[phase].push_back(WitnessOp{i | ((uint32_t)w.kinds[i] << 28), w.ra[i], w.rb[i]});
+            P.level_start[phase].push_back((uint32_t)P.ops[phase].size());
+        }
+    }
+    return P;
+}
+
+}  // namespace
+
+const WitnessProgram& witness_program() {
+    static WitnessProgram P = build_program();
+    return P;
+}
+
+// ================================================================= device
+__device__ __forceinline__ void w_load(const u32* base, u32 ref, const u32* T, const u32* consts, const u32* inputs,
+                                       u32* x) {
+    const u32* p;
+    u32 sp = ref >> 30, idx = ref & WREF_MASK;
+    if (sp == 0) p = T + (size_t)idx * 12;
+    else if (sp == 1) p = consts + (size_t)idx * 12;
+    else p = inputs + (size_t)idx * 12;
+    (void)base;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1], c = q[2];
+    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    x[8] = c.x; x[9] = c.y; x[10] = c.z; x[11] = c.w;
+}
+
+__global__ __launch_bounds__(256) void witness_kernel(const WitnessOp* ops, const u32* level_start, int nlevels,
+                                                      u32* trace, size_t rows, const u32* consts, const u32* inputs) {
+    u32* T = trace + (size_t)blockIdx.x * rows * 12;
+    const u32* in = inputs + (size_t)blockIdx.x * 6 * 12;
+    const u32 P[12] = BLS381_P_LIMBS;
+    const u32 R2[12] = {0x1c341746u, 0xf4df1f34u, 0x09d104f1u, 0x0a76e6a6u, 0x4c95b6d5u, 0x8de5476cu,
+                        0x939d83c0u, 0x67eb88a9u, 0xb519952du, 0x9a793e85u, 0x92cae3aau, 0x11988fe5u};
+    for (int l = 0; l < nlevels; l++) {
+        const u32 lo = level_start[l], hi = level_start[l + 1];
+        for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            const WitnessOp op = ops[i];
+            const u32 kind = op.dst >> 28, row = op.dst & 0x0fffffffu;
+            u32 a[12], b[12], r[12];
+            w_load(T, op.a, T, consts, in, a);
+            if (kind == WK_INV) {
+                // the only inv_nonnative on the path inverts the constant 2 (curves/g2.rs:149-151)
+                const uint4* q = reinterpret_cast<const uint4*>(consts + (size_t)WC_TWO_INV * 12);
+                uint4 v0 = q[0], v1 = q[1], v2 = q[2];
+                r[0] = v0.x; r[1] = v0.y; r[2] = v0.z; r[3] = v0.w; r[4] = v1.x; r[5] = v1.y; r[6] = v1.z; r[7] = v1.w;
+                r[8] = v2.x; r[9] = v2.y; r[10] = v2.z; r[11] = v2.w;
+            } else if (kind == WK_MUL) {
+                w_load(T, op.b, T, consts, in, b);
+                u32 t[12];
+                fp_mul(a, b, t);   // a b / R
+                fp_mul(t, R2, r);  // * R^2 / R = a b
+            } else if (kind == WK_ADD) {
+                w_load(T, op.b, T, consts, in, b);
+                u32 c = 0;
+#pragma unroll
+                for (int k = 0; k < 12; k++) r[k] = addc(a[k], b[k], c);
+                fp_cond_sub_p(r);
+            } else if (kind == WK_SUB) {
+                w_load(T, op.b, T, consts, in, b);
+                u32 bw = 0;
+#pragma unroll
+                for (int k = 0; k < 12; k++) r[k] = subb(a[k], b[k], bw);
+                u32 m = 0u - bw, c = 0;
+#pragma unroll
+                for (int k = 0; k < 12; k++) r[k] = addc(r[k], P[k] & m, c);
+            } else {  // WK_NEG: p - a, and 0 stays 0
+                u32 nz = 0, bw = 0;
+#pragma unroll
+                for (int k = 0; k < 12; k++) nz |= a[k];
+                const u32 m = nz ? 0xffffffffu : 0u;
+#pragma unroll
+                for (int k = 0; k < 12; k++) r[k] = subb(P[k] & m, a[k], bw);
+            }
+            uint4* d = reinterpret_cast<uint4*>(T + (size_t)row * 12);
+            d[0] = make_uint4(r[0], r[1], r[2], r[3]);
+            d[1] = make_uint4(r[4], r[5], r[6], r[7]);
+            d[2] = make_uint4(r[8], r[9], r[10], r[11]);
+        }
+        __syncthreads();
+    }
+}
+
+// inputs: Montgomery {px,py} and {qx0,qx1,qy0,qy1} -> canonical, 6 Fq per proof
+__global__ void witness_inputs_kernel(const u32* g1, const u32* g2, u32* inputs, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 6) return;
+    int e = i / 6, f = i % 6;
+    const u32* src = f < 2 ? g1 + ((size_t)e * 2 + f) * 12 : g2 + ((size_t)e * 4 + (f - 2)) * 12;
+    u32 a[12], one[12] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, r[12];
+    for (int k = 0; k < 12; k++) a[k] = src[k];
+    fp_mul(a, one, r);
+    for (int k = 0; k < 12; k++) inputs[(size_t)i * 12 + k] = r[k];
+}
+// x[e][k] = trace row refs[k] of proof e   /   trace generator rows = inv[e][k]
+__global__ void witness_gather_kernel(const u32* trace, size_t rows, const u32* refs, u32* x, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 12) return;
+    int e = i / 12, k = i % 12;
+    const u32* src = trace + ((size_t)e * rows + (refs[k] & WREF_MASK)) * 12;
+    for (int l = 0; l < 12; l++) x[(size_t)i * 12 + l] = src[l];
+}
+__global__ void witness_scatter_kernel(u32* trace, size_t rows, size_t gen_start, const u32* inv, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 12) return;
+    int e = i / 12, k = i % 12;
+    u32* dst = trace + ((size_t)e * rows + gen_start + k) * 12;
+    for (int l = 0; l < 12; l++) dst[l] = inv[(size_t)i * 12 + l];
+}
+
+static void fill_wconsts(std::vector<uint32_t>& c) {
+    c.assign((size_t)WC_COUNT * 12, 0);
+    c[(size_t)WC_ONE * 12] = 1;
+    c[(size_t)WC_FOUR * 12] = 4;
+    std::memcpy(&c[(size_t)WC_TWO_INV * 12], BLS381_TWO_INV_CANON, 48);
+    const uint32_t* f1[5][2] = {{BLS381_FROB1_1_C0_CANON, BLS381_FROB1_1_C1_CANON}, {BLS381_FROB1_2_C0_CANON, BLS381_FROB1_2_C1_CANON},
+                                {BLS381_FROB1_3_C0_CANON, BLS381_FROB1_3_C1_CANON}, {BLS381_FROB1_4_C0_CANON, BLS381_FROB1_4_C1_CANON},
+                                {BLS381_FROB1_5_C0_CANON, BLS381_FROB1_5_C1_CANON}};
+    const uint32_t* f2[5][2] = {{BLS381_FROB2_1_C0_CANON, BLS381_FROB2_1_C1_CANON}, {BLS381_FROB2_2_C0_CANON, BLS381_FROB2_2_C1_CANON},
+                                {BLS381_FROB2_3_C0_CANON, BLS381_FROB2_3_C1_CANON}, {BLS381_FROB2_4_C0_CANON, BLS381_FROB2_4_C1_CANON},
+                                {BLS381_FROB2_5_C0_CANON, BLS381_FROB2_5_C1_CANON}};
+    for (int i = 0; i < 5; i++)
+        for (int j = 0; j < 2; j++) {
+            std::memcpy(&c[(size_t)(WC_FROB1_BASE + 2 * i + j) * 12], f1[i][j], 48);
+            std::memcpy(&c[(size_t)(WC_FROB2_BASE + 2 * i + j) * 12], f2[i][j], 48);
+        }
+}
+
+#define WCHK(x)                                                                  \
+    do {                                                                         \
+        hipError_t e_ = (x);                                                     \
+        if (e_ != hipSuccess) {                                                  \
+            err = std::string(#x) + ": " + hipGetErrorString(e_);                \
+            return -3;                                                           \
+        }                                                                        \
+    } while (0)
+
+static hipError_t ensure(void*& p, size_t& have, size_t need) {
+    if (need <= have) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; have = 0; }
+    hipError_t e = hipMalloc(&p, need);
+    if (e == hipSuccess) have = need;
+    return e;
+}
+
+int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint64_t* g1, const uint64_t* g2, size_t n,
+                       uint32_t* trace, std::string& err) {
+    const WitnessProgram& P = witness_program();
+    if (!uploaded_) {
+        for (int ph = 0; ph < 2; ph++) {
+            WCHK(hipMalloc((void**)&d_ops_[ph], P.ops[ph].size() * sizeof(WitnessOp)));
+            WCHK(hipMalloc((void**)&d_levels_[ph], P.level_start[ph].size() * 4));
+            WCHK(hipMemcpy(d_ops_[ph], P.ops[ph].data(), P.ops[ph].size() * sizeof(WitnessOp), hipMemcpyHostToDevice));
+            WCHK(hipMemcpy(d_levels_[ph], P.level_start[ph].data(), P.level_start[ph].size() * 4, hipMemcpyHostToDevice));
+        }
+        std::vector<uint32_t> wc;
+        fill_wconsts(wc);
+        WCHK(hipMalloc((void**)&d_consts_, wc.size() * 4));
+        WCHK(hipMemcpy(d_consts_, wc.data(), wc.size() * 4, hipMemcpyHostToDevice));
+        WCHK(hipMalloc((void**)&d_inv_refs_, 48));
+        WCHK(hipMemcpy(d_inv_refs_, P.inv_input_refs, 48, hipMemcpyHostToDevice));
+        uploaded_ = true;
+    }
+    const size_t CH = 64;  // proofs per pass: 64 x 6.8 MB of trace
+    for (size_t off = 0; off < n; off += CH) {
+        int m = (int)std::min(CH, n - off);
+        size_t tbytes = (size_t)m * P.n_rows * 48;
+        WCHK(ensure(d_trace_, trace_bytes_, tbytes));
+        WCHK(ensure(d_inputs_, inputs_bytes_, (size_t)m * 6 * 48));
+        WCHK(ensure(d_x_, x_bytes_, (size_t)m * 576 * 2));
+        WCHK(ensure(d_g_, g_bytes_, (size_t)m * 288));
+        u32* d_g1 = (u32*)d_g_;
+        u32* d_g2 = d_g1 + (size_t)m * 24;
+        WCHK(hipMemcpyAsync(d_g1, g1 + off * 12, (size_t)m * 96, hipMemcpyHostToDevice, stream));
+        WCHK(hipMemcpyAsync(d_g2, g2 + off * 24, (size_t)m * 192, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(witness_inputs_kernel, dim3((m * 6 + 63) / 64), dim3(64), 0, stream, d_g1, d_g2, (u32*)d_inputs_, m);
+        WCHK(hipGetLastError());
+        hipLaunchKernelGGL(witness_kernel, dim3(m), dim3(256), 0, stream, d_ops_[0], d_levels_[0],
+                           (int)P.level_start[0].size() - 1, (u32*)d_trace_, P.n_rows, d_consts_, (const u32*)d_inputs_);
+        WCHK(hipGetLastError());
+        u32* d_x = (u32*)d_x_;
+        u32* d_inv = d_x + (size_t)m * 144;
+        hipLaunchKernelGGL(witness_gather_kernel, dim3((m * 12 + 63) / 64), dim3(64), 0, stream, (const u32*)d_trace_,
+                           P.n_rows, d_inv_refs_, d_x, m);
+        WCHK(hipGetLastError());
+        int rc = inv(ctx, d_x, (size_t)m, d_inv);
+        if (rc) { err = "Fq12 inversion inside the witness trace failed (zero Miller value?)"; return rc; }
+        hipLaunchKernelGGL(witness_scatter_kernel, dim3((m * 12 + 63) / 64), dim3(64), 0, stream, (u32*)d_trace_, P.n_rows,
+                           P.gen_start, d_inv, m);
+        WCHK(hipGetLastError());
+        hipLaunchKernelGGL(witness_kernel, dim3(m), dim3(256), 0, stream, d_ops_[1], d_levels_[1],
+                           (int)P.level_start[1].size() - 1, (u32*)d_trace_, P.n_rows, d_consts_, (const u32*)d_inputs_);
+        WCHK(hipGetLastError());
+        WCHK(hipMemcpyAsync(trace + off * P.n_rows * 12, d_trace_, tbytes, hipMemcpyDeviceToHost, stream));
+        WCHK(hipStreamSynchronize(stream));
+    }
+    return 0;
+}
+
+void WitnessDevice::release() {
+    for (int ph = 0; ph < 2; ph++) { if (d_ops_[ph]) (void)hipFree(d_ops_[ph]); if (d_levels_[ph]) (void)hipFree(d_levels_[ph]); d_ops_[ph] = nullptr; d_levels_[ph] = nullptr; }
+    for (void* p : {(void*)d_consts_, (void*)d_inv_refs_, d_trace_, d_inputs_, d_x_, d_g_}) if (p) (void)hipFree(p);
+    d_consts_ = nullptr; d_inv_refs_ = nullptr; d_trace_ = d_inputs_ = d_x_ = d_g_ = nullptr;
+    trace_bytes_ = inputs_bytes_ = x_bytes_ = g_bytes_ = 0;
+    uploaded_ = false;
+}
+
+}  // namespace bls381

@@ -1,22 +1,76 @@
-// Witness-trace generation for the single-pair pairing circuit (placeholder interface; see witness.cpp).
+// Witness trace of the single-pair pairing circuit: the value of every non-native Fq operation the
+// reference's circuit builders create, in builder call order.
+//
+// Host side: a symbolic replay of the builder call sequence
+//   G2PreparedTarget::from   /root/reference/src/curves/g2.rs:148-178 (steps :59-129)
+//   multi_miller_loop        /root/reference/src/miller_loop.rs:19-79
+//   final_exponentiation     /root/reference/src/final_exponentiation.rs:12-64
+//   frobenius_map/pow_target /root/reference/src/final_exponentiation_helpers.rs:14-85
+//   Fq12/Fq6/Fq2 gadgets     /root/reference/src/fields/{fq12,fq6,fq2}_target.rs
+// producing one record per row (operation kind + operand references), level-scheduled so that a
+// workgroup can evaluate each dependency level in parallel.
+// Device side: one workgroup per proof walks the levels; rows are canonical 12 x u32 limbs
+// (/root/reference/src/fields/fq_target.rs:280-293).
 #pragma once
 #include <hip/hip_runtime.h>
+
 #include <cstdint>
 #include <string>
 #include <vector>
 
 namespace bls381 {
 
+enum WitnessKind : uint8_t { WK_ADD = 0, WK_SUB = 1, WK_MUL = 2, WK_NEG = 3, WK_INV = 4, WK_GEN = 5 };
+
+// operand reference: bits 30..31 = space (0 trace row, 1 constant, 2 circuit input), bits 0..29 = index
+enum { WREF_ROW = 0u << 30, WREF_CONST = 1u << 30, WREF_INPUT = 2u << 30, WREF_MASK = (1u << 30) - 1 };
+
+struct WitnessOp {
+    uint32_t dst;   // row index | kind << 28
+    uint32_t a, b;  // operand references (b unused for neg / inv)
+};
+
+// canonical constants the circuit uses (FqTarget::constant values)
+enum WitnessConst {
+    WC_ZERO = 0, WC_ONE = 1, WC_FOUR = 2, WC_TWO_INV = 3,
+    WC_FROB1_BASE = 4,   // + 2*(i-1) + {0,1}, i = 1..5
+    WC_FROB2_BASE = 14,  // + 2*(i-1) + {0,1}, i = 1..5 (c1 = 0)
+    WC_COUNT = 24,
+};
+
 struct WitnessProgram {
     size_t n_rows = 0;
-    std::vector<uint8_t> kinds;  // per row: 0 add, 1 sub, 2 mul, 3 neg, 4 inv, 5 generator output
+    std::vector<uint8_t> kinds;           // per row
+    size_t gen_start = 0;                 // first of the 12 generator-output rows
+    uint32_t inv_input_refs[12];          // rows holding x (MyFq12 order) that Fq12InverseGenerator inverts
+    std::vector<WitnessOp> ops[2];        // phase 0: rows before the generator output, phase 1: rows after
+    std::vector<uint32_t> level_start[2]; // per phase, nlevels + 1 offsets into ops[phase]
+    size_t counts[6] = {0, 0, 0, 0, 0, 0};
 };
 const WitnessProgram& witness_program();
 
-struct WitnessDevice {
-    int run(hipStream_t stream, const uint4* consts, const uint64_t* g1, const uint64_t* g2, size_t n, uint32_t* trace,
-            std::string& err);
+struct bls381_ctx_fwd;
+
+class WitnessDevice {
+   public:
+    // Runs n proofs.  g1/g2: host arrays in the ABI layout (Montgomery).  trace: host, n * n_rows * 12 u32.
+    // `run_inverse` performs the Fq12 inversion of n values given as device canonical limbs (n x 144 u32, MyFq12
+    // order) into device canonical limbs; it is supplied by the context (lane-group programs inv1/inv2).
+    typedef int (*inverse_fn)(void* ctx, const uint32_t* x_dev, size_t n, uint32_t* inv_dev);
+    int run(hipStream_t stream, void* ctx, inverse_fn inv, const uint64_t* g1, const uint64_t* g2, size_t n,
+            uint32_t* trace, std::string& err);
     void release();
+
+   private:
+    bool uploaded_ = false;
+    WitnessOp* d_ops_[2] = {nullptr, nullptr};
+    uint32_t* d_levels_[2] = {nullptr, nullptr};
+    uint32_t* d_consts_ = nullptr;
+    uint32_t* d_inv_refs_ = nullptr;
+    void* d_trace_ = nullptr;  size_t trace_bytes_ = 0;
+    void* d_inputs_ = nullptr; size_t inputs_bytes_ = 0;
+    void* d_x_ = nullptr;      size_t x_bytes_ = 0;
+    void* d_g_ = nullptr;      size_t g_bytes_ = 0;
 };
 
 }  // namespace bls381

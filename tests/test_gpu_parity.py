@@ -229,3 +229,19 @@ def test_full_batch_65536_against_c_oracle_and_bilinearity(ctx, CO):
     prod = ctx.fq12_mul_batch(out[:m], neg)
     one = H.fq12_array([R.FQ12_ONE])[0]
     assert all(np.array_equal(prod[i], one) for i in range(m))
+
+
+def test_pairing_witness_trace(ctx):
+    """Every row of the witness trace (canonical 12 x u32 limbs) against the CPU replay of the
+    circuit's builder calls, for three proofs."""
+    import witness_ref as W
+    ps, qs = H.random_pairs(3, 808)
+    trace = ctx.pairing_witness_batch(H.g1_array(ps), H.g2_array(qs))
+    assert trace.shape == (3, 141376, 12)
+    for e in range(3):
+        tr, out = W.pairing_witness(ps[e], qs[e])
+        want = np.array([R.fq_to_u32_limbs(v) for _, v in tr.rows], dtype=np.uint32)
+        bad = np.nonzero((trace[e] != want).any(axis=1))[0]
+        assert bad.size == 0, (e, bad[:5], [tr.rows[i][0] for i in bad[:5]])
+        # the last row group is the pairing value in MyFq12 order
+        assert R.myfq12_to_fq12(out) == R.native_pairing([ps[e]], [qs[e]])

@@ -98,3 +98,17 @@ def test_program_statistics():
     # 63 doublings + 5 additions: the multiplication count must stay at or below the reference's model
     assert 6000 < p["n_fmul"] <= 7141
     assert S.get_program("fe2", 8, 0)["n_fmul"] <= 8119
+
+
+def test_witness_program_rows_match_circuit_op_totals():
+    """src/pairing.rs:13-20 after G2PreparedTarget::from: 141,364 Fq operations + 12 generator outputs."""
+    import numpy as np
+    import witness_ref as W
+    import plonky2_bls12_381_pairing_amd as B
+    kinds = B.witness_kinds()
+    assert B.witness_rows() == len(kinds) == 141376
+    cnt = np.bincount(kinds, minlength=6)
+    assert dict(add=cnt[0], sub=cnt[1], mul=cnt[2], neg=cnt[3], inv=cnt[4], gen=cnt[5]) == W.EXPECTED_COUNTS
+    tr, _ = W.pairing_witness(R.G1_GEN, R.G2_GEN)
+    names = ["add", "sub", "mul", "neg", "inv", "gen"]
+    assert all(names[kinds[i]] == tr.rows[i][0] for i in range(len(kinds)))
