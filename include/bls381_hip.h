@@ -123,6 +123,11 @@ int bls381_final_exp_batch_dev(bls381_ctx*, const uint64_t* in_fq12_dev, size_t 
  * Host-only: needs no GPU. */
 int bls381_debug_program(const char* which, int lanes_per_group, int lds_slots, uint32_t* hdrs, uint32_t* descs,
                          size_t capacity_steps, uint32_t info[8]);
+/* Element-wise Montgomery products a[i] * b[i] / 2^384 mod p of n Fq pairs (12 x u32 limbs each)
+ * with the hand-scheduled multiplier (out) and the plain-C form it is cross-checked against
+ * (out_plain). */
+int bls381_debug_fp_mul(bls381_ctx*, const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out,
+                        uint32_t* out_plain);
 /* Constant table (C_COUNT x 12 u32). */
 int bls381_debug_constants(uint32_t* out, size_t capacity_fp);
 /* Timing of the most recent pairing / Miller-loop / final-exponentiation batch call on this context

@@ -728,6 +728,36 @@ extern "C" int bls381_last_timing(bls381_ctx* c, float ms[4]) {
     return 0;
 }
 
+// element-wise Montgomery products with both multiplier implementations (self-check of the
+// hand-scheduled fp_mul against the plain-C form and, in the tests, against big integers)
+__global__ void fp_mul_check_kernel(const u32* a, const u32* b, u32* out, u32* out_plain, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 x[12], y[12], r[12], q[12];
+    for (int k = 0; k < 12; k++) { x[k] = a[(size_t)i * 12 + k]; y[k] = b[(size_t)i * 12 + k]; }
+    fp_mul(x, y, r);
+    fp_mul_plain(x, y, q);
+    for (int k = 0; k < 12; k++) { out[(size_t)i * 12 + k] = r[k]; out_plain[(size_t)i * 12 + k] = q[k]; }
+}
+extern "C" int bls381_debug_fp_mul(bls381_ctx* c, const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out,
+                                   uint32_t* out_plain) {
+    CTX_GUARD(c);
+    if (n == 0) return 0;
+    if (!a || !b || !out || !out_plain) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    int rc;
+    if ((rc = h2d(c, c->user_in, a, n * 48))) return rc;
+    if ((rc = h2d(c, c->user_in2, b, n * 48))) return rc;
+    HIPCHK(c->user_out.ensure(n * 96));
+    u32* o = (u32*)c->user_out.p;
+    hipLaunchKernelGGL(fp_mul_check_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream,
+                       (const u32*)c->user_in.p, (const u32*)c->user_in2.p, o, o + n * 12, (int)n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, o, n * 48, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_plain, o + n * 12, n * 48, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // sustained v_mad_u64_u32 rate: 8 independent accumulators per lane, 8 waves per SIMD
 __global__ void mac_rate_kernel(u32* out, u32 seed, int iters) {
     u32 a = seed + threadIdx.x, b = seed * 3 + blockIdx.x;

@@ -20,6 +20,7 @@ struct Fp {
     u32 l[12];
 };
 
+// Portable carry helpers (used by the plain-C reference forms only).
 __device__ __forceinline__ u32 addc(u32 a, u32 b, u32& carry) {
     u64 s = (u64)a + b + carry;
     carry = (u32)(s >> 32);
@@ -31,15 +32,60 @@ __device__ __forceinline__ u32 subb(u32 a, u32 b, u32& borrow) {
     return (u32)d;
 }
 
+// Carry chains on the hardware carry bit.  The carry lives in an SGPR pair the compiler allocates
+// (one bit per lane), so consecutive links are single VALU instructions and the scheduler is free
+// to interleave independent chains.
+typedef u64 carry_t;
+__device__ __forceinline__ u32 add_co(u32 a, u32 b, carry_t& c) {
+    u32 r;
+    asm("v_add_co_u32 %0, %1, %2, %3" : "=v"(r), "=s"(c) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ u32 addc_co(u32 a, u32 b, carry_t& c) {
+    u32 r;
+    asm("v_addc_co_u32 %0, %1, %2, %3, %1" : "=v"(r), "+s"(c) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ u32 sub_co(u32 a, u32 b, carry_t& c) {
+    u32 r;
+    asm("v_sub_co_u32 %0, %1, %2, %3" : "=v"(r), "=s"(c) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ u32 subb_co(u32 a, u32 b, carry_t& c) {
+    u32 r;
+    asm("v_subb_co_u32 %0, %1, %2, %3, %1" : "=v"(r), "+s"(c) : "v"(a), "v"(b));
+    return r;
+}
+// all-ones where the chain ended with a borrow / carry, else zero
+__device__ __forceinline__ u32 carry_mask(carry_t& c) {
+    u32 r;
+    asm("v_subb_co_u32 %0, %1, 0, 0, %1" : "=v"(r), "+s"(c));
+    return r;
+}
+// (mask & a) | (~mask & b)
+__device__ __forceinline__ u32 bitselect(u32 mask, u32 a, u32 b) {
+    u32 r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
+
+// n-limb a -= q when a >= q (one round of the reduction ladder); q >= 2^(32(n-1)) is not required
+template <int N>
+__device__ __forceinline__ void cond_sub(u32* a, const u32* q) {
+    u32 t[N];
+    carry_t c;
+    t[0] = sub_co(a[0], q[0], c);
+#pragma unroll
+    for (int i = 1; i < N; i++) t[i] = subb_co(a[i], q[i], c);
+    const u32 keep = carry_mask(c);  // borrow: a < q, keep a
+#pragma unroll
+    for (int i = 0; i < N; i++) a[i] = bitselect(keep, a[i], t[i]);
+}
+
 // r = a - p if a >= p else a, for a < 2p
 __device__ __forceinline__ void fp_cond_sub_p(u32* a) {
     const u32 P[12] = BLS381_P_LIMBS;
-    u32 t[12], bw = 0;
-#pragma unroll
-    for (int i = 0; i < 12; i++) t[i] = subb(a[i], P[i], bw);
-    u32 keep = 0u - bw;  // all ones when a < p
-#pragma unroll
-    for (int i = 0; i < 12; i++) a[i] = (a[i] & keep) | (t[i] & ~keep);
+    cond_sub<12>(a, P);
 }
 
 // 24-limb product t = a * b (operand scanning)
@@ -83,10 +129,16 @@ __device__ __forceinline__ void mont_redc(u32* t, u32* r) {
     fp_cond_sub_p(r);
 }
 
-__device__ __forceinline__ void fp_mul(const u32* a, const u32* b, u32* r) {
+// Reference form: separate product and reduction in plain C (kept for cross-checking the
+// hand-scheduled multiplier below on the GPU).
+__device__ __forceinline__ void fp_mul_plain(const u32* a, const u32* b, u32* r) {
     u32 t[24];
     mul_wide(a, b, t);
     mont_redc(t, r);
 }
+
+// fp_mul (the hand-scheduled Montgomery multiplier) and the literal-operand reduction blocks are
+// generated: fp_asm_gen.h.
+__device__ __forceinline__ void fp_mul(const u32* a, const u32* b, u32* r);
 
 }  // namespace bls381

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "fp_dev.h"
+#include "fp_asm_gen.h"
 #include "vm_format.h"
 
 namespace bls381 {
@@ -71,10 +72,12 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
     const uint4* dptr = reinterpret_cast<const uint4*>(A.descs) + (size_t)role * 2;
     uint4 nd0 = dptr[0], nd1 = dptr[1];
 
+    StepHdr nh = A.hdrs[0];
     for (int s = 0; s < A.nsteps; s++) {
-        const StepHdr h = A.hdrs[s];
+        const StepHdr h = nh;
         const uint4 d0 = nd0, d1 = nd1;
-        if (s + 1 < A.nsteps) {
+        if (s + 1 < A.nsteps) {  // next step's header and descriptor travel while this step computes
+            nh = A.hdrs[s + 1];
             const uint4* np = dptr + (size_t)(s + 1) * K * 2;
             nd0 = np[0]; nd1 = np[1];
         }
@@ -110,31 +113,21 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                         const u32 m = (w & 0x8000u) ? 0xffffffffu : 0u;
                         u32 x[12];
                         lds_load(w & 0x7fffu, x);
-                        u32 c = m & 1u;
+                        // acc += x, or acc += ~x + 1 (two's complement, sign-extended into limb 12)
+                        u32 y[12];
 #pragma unroll
-                        for (int i = 0; i < 12; i++) acc[i] = addc(acc[i], x[i] ^ m, c);
-                        acc[12] = acc[12] + m + c;
+                        for (int i = 0; i < 12; i++) y[i] = x[i] ^ m;
+                        lin_accumulate(acc, y, m);
                     }
                 }
             }
             // conditional subtraction of 2^j * p, j = rounds-1 .. 0
             const u32 rounds = (h.max_terms >> 8) & 0xffu;
-#pragma unroll
-            for (int j = 4; j >= 0; j--) {
-                if ((int)rounds > j) {
-                    const uint4* row = kp_lds + (1u << j) * 4;
-                    uint4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
-                    u32 q[13];
-                    unpack3(r0, r1, r2, q);
-                    q[12] = r3.x;
-                    u32 t[13], bw = 0;
-#pragma unroll
-                    for (int i = 0; i < 13; i++) t[i] = subb(acc[i], q[i], bw);
-                    const u32 keep = 0u - bw;
-#pragma unroll
-                    for (int i = 0; i < 13; i++) acc[i] = (acc[i] & keep) | (t[i] & ~keep);
-                }
-            }
+            if (rounds > 4) cond_sub_kp<4>(acc);
+            if (rounds > 3) cond_sub_kp<3>(acc);
+            if (rounds > 2) cond_sub_kp<2>(acc);
+            if (rounds > 1) cond_sub_kp<1>(acc);
+            if (rounds > 0) cond_sub_kp<0>(acc);
             if (on) lds_store(W(0), acc);
         } else {  // ST_COPY: every lane reads before any lane writes
             const u32 kind = (d0.x >> 8) & 0xffu;

@@ -5,6 +5,7 @@
 
 #include "bls381_constants.h"
 #include "fp_dev.h"
+#include "fp_asm_gen.h"
 
 namespace bls381 {
 
@@ -385,25 +386,31 @@ __global__ __launch_bounds__(256) void witness_kernel(const WitnessOp* ops, cons
                 fp_mul(t, R2, r);  // * R^2 / R = a b
             } else if (kind == WK_ADD) {
                 w_load(T, op.b, T, consts, in, b);
-                u32 c = 0;
+                carry_t c;
+                r[0] = add_co(a[0], b[0], c);
 #pragma unroll
-                for (int k = 0; k < 12; k++) r[k] = addc(a[k], b[k], c);
+                for (int k = 1; k < 12; k++) r[k] = addc_co(a[k], b[k], c);
                 fp_cond_sub_p(r);
             } else if (kind == WK_SUB) {
                 w_load(T, op.b, T, consts, in, b);
-                u32 bw = 0;
+                carry_t c;
+                r[0] = sub_co(a[0], b[0], c);
 #pragma unroll
-                for (int k = 0; k < 12; k++) r[k] = subb(a[k], b[k], bw);
-                u32 m = 0u - bw, c = 0;
+                for (int k = 1; k < 12; k++) r[k] = subb_co(a[k], b[k], c);
+                const u32 m = carry_mask(c);  // borrow: add p back
+                carry_t c2;
+                r[0] = add_co(r[0], P[0] & m, c2);
 #pragma unroll
-                for (int k = 0; k < 12; k++) r[k] = addc(r[k], P[k] & m, c);
+                for (int k = 1; k < 12; k++) r[k] = addc_co(r[k], P[k] & m, c2);
             } else {  // WK_NEG: p - a, and 0 stays 0
-                u32 nz = 0, bw = 0;
+                u32 nz = 0;
 #pragma unroll
                 for (int k = 0; k < 12; k++) nz |= a[k];
                 const u32 m = nz ? 0xffffffffu : 0u;
+                carry_t c;
+                r[0] = sub_co(P[0] & m, a[0], c);
 #pragma unroll
-                for (int k = 0; k < 12; k++) r[k] = subb(P[k] & m, a[k], bw);
+                for (int k = 1; k < 12; k++) r[k] = subb_co(P[k] & m, a[k], c);
             }
             uint4* d = reinterpret_cast<uint4*>(T + (size_t)row * 12);
             d[0] = make_uint4(r[0], r[1], r[2], r[3]);

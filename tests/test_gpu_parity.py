@@ -245,3 +245,26 @@ def test_pairing_witness_trace(ctx):
         assert bad.size == 0, (e, bad[:5], [tr.rows[i][0] for i in bad[:5]])
         # the last row group is the pairing value in MyFq12 order
         assert R.myfq12_to_fq12(out) == R.native_pairing([ps[e]], [qs[e]])
+
+
+def test_fp_mul_kernel_against_big_integers(ctx):
+    """The hand-scheduled Montgomery multiplier on 2^16 random pairs plus edge values (0, 1, p-1,
+    R mod p, all-ones below 2p) against Python integers and against the plain-C form."""
+    import ctypes as C
+    import random
+    from plonky2_bls12_381_pairing_amd import _lib
+    rng = random.Random(99)
+    edge = [0, 1, R.P - 1, R.MONT_R, R.P - 2, (1 << 381) - 1, 2 * R.P - 1, (1 << 382) - 1, 0xffffffff, 1 << 352]
+    pairs = [(x, y) for x in edge for y in edge if x * y < R.P << 384]
+    pairs += [(rng.randrange(R.P), rng.randrange(R.P)) for _ in range(65536 - len(pairs))]
+    n = len(pairs)
+    a = np.array([R.fq_to_u32_limbs(x) for x, _ in pairs], dtype=np.uint32)
+    b = np.array([R.fq_to_u32_limbs(y) for _, y in pairs], dtype=np.uint32)
+    out = np.empty_like(a)
+    plain = np.empty_like(a)
+    p32 = lambda v: v.ctypes.data_as(_lib.u32p)
+    _lib.check(_lib.lib.bls381_debug_fp_mul(ctx.handle, p32(a), p32(b), n, p32(out), p32(plain)))
+    rinv = pow(1 << 384, -1, R.P)
+    want = np.array([R.fq_to_u32_limbs(x * y * rinv % R.P) for x, y in pairs], dtype=np.uint32)
+    assert np.array_equal(out, want)
+    assert np.array_equal(plain, want)
