@@ -116,6 +116,7 @@ struct bls381_ctx {
     int device = 0;
     int K = 8;
     int lds_slots = 0;
+    bool auto_geometry = false;  // defaults requested: per-program lane-group width
     hipStream_t stream = nullptr;
     std::map<std::string, DevProgram> progs;
     uint4* d_consts = nullptr;
@@ -128,10 +129,20 @@ struct bls381_ctx {
     WitnessDevice wit;
 };
 
+// Lane-group width per program: the Miller loop has enough independent multiplications per step to
+// fill 16 lanes (and gains latency hiding from twice the waves at the same LDS per pairing); the
+// final exponentiation's cyclotomic squarings do not.
+static void program_geometry(const bls381_ctx* c, const std::string& which, int& K, int& slots) {
+    K = c->K; slots = c->lds_slots;
+    if (c->auto_geometry && (which == "miller" || which == "g2prep")) { K = 16; slots = 64; }
+}
+
 static int upload_program(bls381_ctx* c, const std::string& which) {
     DevProgram dp;
     try {
-        dp.host = schedule(build_named(which), c->K, c->lds_slots, which);
+        int K, slots;
+        program_geometry(c, which, K, slots);
+        dp.host = schedule(build_named(which), K, slots, which);
     } catch (std::exception& e) {
         return fail(BLS381_ERR_INVALID, std::string("program ") + which + ": " + e.what());
     }
@@ -146,6 +157,7 @@ static int upload_program(bls381_ctx* c, const std::string& which) {
 extern "C" int bls381_ctx_create_ex(bls381_ctx** out, int device_id, int K, int lds_slots) {
     if (!out) return fail(BLS381_ERR_INVALID, "out is NULL");
     *out = nullptr;
+    const bool auto_geometry = (K == 0 && lds_slots == 0);
     if (K == 0) K = 8;
     if (!valid_k(K)) return fail(BLS381_ERR_INVALID, "lanes_per_group must be 6, 8, 9, 12 or 16");
     if (lds_slots == 0) lds_slots = default_slots(K);
@@ -161,7 +173,7 @@ extern "C" int bls381_ctx_create_ex(bls381_ctx** out, int device_id, int K, int 
     size_t lds_bytes = (size_t)lds_slots * 48 * (4 * (64 / K)) + KP_ROWS * 64;
     if (lds_bytes > 160 * 1024) return fail(BLS381_ERR_INVALID, "lds_slots does not fit the 160 KiB LDS");
     bls381_ctx* c = new bls381_ctx();
-    c->device = device_id; c->K = K; c->lds_slots = lds_slots;
+    c->device = device_id; c->K = K; c->lds_slots = lds_slots; c->auto_geometry = auto_geometry;
     int rc = 0;
     auto bail = [&](int code) { bls381_ctx_destroy(c); return code; };
     if (hipStreamCreate(&c->stream) != hipSuccess) return bail(fail(BLS381_ERR_HIP, "hipStreamCreate failed"));
@@ -234,7 +246,7 @@ static int run_program(bls381_ctx* c, const char* which, const void* gin, void* 
     const DevProgram& p = it->second;
     HIPCHK(c->bufTmp.ensure(soa_bytes(std::max(1, p.host.n_tmp_slots), npad)));
     hipError_t e;
-    switch (c->K) {
+    switch (p.host.K) {
         case 6: e = launch_vm_k<6>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)c->bufTmp.p, n, npad); break;
         case 8: e = launch_vm_k<8>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)c->bufTmp.p, n, npad); break;
         case 9: e = launch_vm_k<9>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)c->bufTmp.p, n, npad); break;

@@ -142,6 +142,31 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         prio[i] = best + w;
     }
 
+    // ---- bound analysis: a LIN result may stay unreduced (value <= bound * p) when every consumer
+    // tolerates it.  FMUL needs bound(a) * bound(b) * p^2 < p * 2^384, i.e. the product of bounds <= 9;
+    // stores need a canonical value; 12 limbs hold at most 9p.
+    std::vector<int> bound(n, 1), lin_rounds(n, 0), lin_bias(n, 0);
+    for (int i = 0; i < n; i++) {
+        if (N[i].kind != NK_LIN) continue;
+        int total = 0, bias = 0;
+        for (auto& t : N[i].terms) { total += bound[t.node]; if (t.neg) bias += bound[t.node]; }
+        int target = 9;
+        for (int s2 : succ[i]) {
+            if (N[s2].kind == NK_STOREOUT) target = 1;
+            else if (N[s2].kind == NK_FMUL) target = std::min(target, 3);
+            else target = std::min(target, 2);
+        }
+        if (succ[i].empty()) target = 1;
+        int r = 0;
+        while (std::max(1, total - (1 << r) + 1) > target) r++;
+        if (bias > 16 || total > 31 || r > 5) throw std::runtime_error("scheduler: LIN bound out of range");
+        lin_rounds[i] = r; lin_bias[i] = bias;
+        bound[i] = std::max(1, total - (1 << r) + 1);
+    }
+    for (int i = 0; i < n; i++)
+        if (N[i].kind == NK_FMUL && bound[N[i].a] * bound[N[i].b] > 9)
+            throw std::runtime_error("scheduler: FMUL operand bounds too large");
+
     // ---- pass 1: list scheduling into K-wide single-class steps
     const int WINDOW = 600;
     std::vector<char> done(n, 0);
@@ -164,7 +189,17 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
             if (prio[a] != prio[b]) return prio[a] > prio[b];
             return a < b;
         });
-        if ((int)c.size() > K) c.resize(K);
+        if ((int)c.size() > K) {
+            if (cls == OC_LIN) {
+                // keep the most urgent op, fill the step with the ops closest to it in cost
+                int lead = c[0];
+                auto cost = [&](int x) { return (int)N[x].terms.size() * 34 + lin_rounds[x] * 29; };
+                std::stable_sort(c.begin() + 1, c.end(), [&](int a, int b) {
+                    return std::abs(cost(a) - cost(lead)) < std::abs(cost(b) - cost(lead));
+                });
+            }
+            c.resize(K);
+        }
         RawStep st; st.cls = (OpClass)cls; st.ops = c;
         std::set<int> chosen(c.begin(), c.end());
         std::vector<int> nr;
@@ -288,6 +323,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         emit_copy_steps(spills_b);
         // 4. the step itself
         StepHdr h; h.max_terms = 0;
+        int step_rounds = 0;
         h.type = st.cls == OC_FMUL ? ST_FMUL : (st.cls == OC_LIN ? ST_LIN : ST_COPY);
         for (int r = 0; r < K; r++) {
             OpDesc d; std::memset(&d, 0, sizeof d);
@@ -305,13 +341,11 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                         assert(nt <= LIN_MAX_TERMS);
                         d.hdr |= (uint32_t)nt << 8;
                         d.w[0] = (uint16_t)dst_slot[op];
-                        int nneg = 0;
-                        for (int t = 0; t < nt; t++) {
+                        for (int t = 0; t < nt; t++)
                             d.w[1 + t] = (uint16_t)(src_slot[nd.terms[t].node] | (nd.terms[t].neg ? 0x8000 : 0));
-                            nneg += nd.terms[t].neg ? 1 : 0;
-                        }
-                        d.hdr |= (uint32_t)nneg << 16;  // bias multiple: acc starts at nneg * p
+                        d.hdr |= (uint32_t)lin_bias[op] << 16;  // acc starts at bias * p >= sum of negated terms
                         h.max_terms = std::max<uint32_t>(h.max_terms, nt);
+                        step_rounds = std::max(step_rounds, lin_rounds[op]);
                         P.n_lin++; P.n_lin_terms += nt;
                         break;
                     }
@@ -328,13 +362,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
             }
             P.descs.push_back(d);
         }
-        if (st.cls == OC_LIN) {
-            // acc <= max_terms * p, so r rounds of conditional subtraction (2^(r-1) p ... p) with
-            // 2^r > max_terms leave a canonical value
-            uint32_t r = 0;
-            while ((1u << r) <= h.max_terms) r++;
-            h.max_terms |= r << 8;
-        }
+        if (st.cls == OC_LIN) h.max_terms |= (uint32_t)step_rounds << 8;  // ladder 2^(r-1) p ... p
         P.hdrs.push_back(h);
         if (st.cls == OC_FMUL) P.n_fmul_steps++;
         else if (st.cls == OC_LIN) P.n_lin_steps++;

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             }
             // conditional subtraction of 2^j * p, j = rounds-1 .. 0
             const u32 rounds = (h.max_terms >> 8) & 0xffu;
-            if (rounds > 4) cond_sub_kp<4>(acc);
+            if (rounds > 4) cond_sub_kp<4>(acc);  // 16p
             if (rounds > 3) cond_sub_kp<3>(acc);
             if (rounds > 2) cond_sub_kp<2>(acc);
             if (rounds > 1) cond_sub_kp<1>(acc);

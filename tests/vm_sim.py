@@ -57,24 +57,25 @@ def run_program(prog, gin, strict=True):
             if typ == ST_FMUL:
                 a, b = lds[w[1]], lds[w[2]]
                 assert a is not None and b is not None, "FMUL reads an empty slot"
+                assert a * b < P << 384, "FMUL operands exceed the Montgomery bound"
                 writes.append(("lds", w[0], a * b * RINV % P))
             elif typ == ST_LIN:
                 nt = (d[0] >> 8) & 0xff
                 kb = (d[0] >> 16) & 0xff
-                assert nt <= (mt & 0xff)
+                assert nt <= (mt & 0xff) and kb <= 16
                 acc = kb * P
-                nneg = 0
                 for t in range(nt):
                     v = lds[w[1 + t] & 0x7fff]
                     assert v is not None, "LIN reads an empty slot"
-                    if w[1 + t] & 0x8000:
-                        acc -= v; nneg += 1
-                    else:
-                        acc += v
-                assert nneg == kb and acc >= 0
+                    acc += -v if w[1 + t] & 0x8000 else v
+                assert 0 <= acc < 1 << 416, "13-limb accumulator out of range"
                 rounds = (mt >> 8) & 0xff
-                assert acc < (1 << rounds) * P, "not enough reduction rounds"
-                writes.append(("lds", w[0], acc % P))
+                assert rounds <= 5
+                for j in range(rounds - 1, -1, -1):         # the kernel's ladder 2^(r-1) p ... p
+                    if acc >= (P << j):
+                        acc -= P << j
+                assert acc < 1 << 384, "unreduced value does not fit 12 limbs"
+                writes.append(("lds", w[0], acc))
             else:
                 kind = (d[0] >> 8) & 0xff
                 if kind == CK_IN:
@@ -87,7 +88,7 @@ def run_program(prog, gin, strict=True):
                     assert lds[w[1]] is not None
                     writes.append(("tmp", w[0], lds[w[1]]))
                 else:
-                    assert lds[w[1]] is not None
+                    assert lds[w[1]] is not None and lds[w[1]] < P, "stored value is not canonical"
                     writes.append(("out", w[0], lds[w[1]]))
         seen = set()
         for where, idx, v in writes:
