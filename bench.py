@@ -157,9 +157,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cores = min(16, os.cpu_count() or 1)
             CO.set_threads(cores)
-            nsamp = 64 * cores
+            probe = np.arange(8 * cores) * 37 % BATCH
+            t1 = time.perf_counter()
+            CO.pairing_batch(g1[probe], g2[probe])                  # warms the threads, sizes the sample
+            rate = len(probe) / (time.perf_counter() - t1)
+            nsamp = int(min(BATCH, max(len(probe), rate * 12.0)))   # about 12 s of CPU work
             idx = np.arange(nsamp) * 37 % BATCH
-            CO.pairing_batch(g1[idx[:cores]], g2[idx[:cores]])      # warm the threads
             t1 = time.perf_counter()
             CO.pairing_batch(g1[idx], g2[idx])
             dt = time.perf_counter() - t1

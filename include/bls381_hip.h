@@ -119,7 +119,7 @@ int bls381_final_exp_batch_dev(bls381_ctx*, const uint64_t* in_fq12_dev, size_t 
 /* Builds and schedules the step program `which` ("miller", "fe1", "fe2", "g2prep", "ell", "fq12mul",
  * "easy2", "hardgen", "inv1", "inv2", "frob1", "frob2") for groups of K lanes and copies it into
  * caller buffers: hdrs = nsteps x 2 u32, descs = nsteps x K x 8 u32.  info[8] receives
- * {K, nsteps, lds_slots, tmp_slots, n_in, n_out, n_fmul, n_lin}.  Pass NULL buffers to query sizes.
+ * {K, nsteps, lds_slots, tmp_slots, n_in, n_out, multiply-accumulates executed (300 per product, 444 per two-product sum), n_lin}.  Pass NULL buffers to query sizes.
  * Host-only: needs no GPU. */
 int bls381_debug_program(const char* which, int lanes_per_group, int lds_slots, uint32_t* hdrs, uint32_t* descs,
                          size_t capacity_steps, uint32_t info[8]);

@@ -29,6 +29,12 @@ int Dag::fmul(int a, int b) {
     nodes.push_back(n);
     return (int)nodes.size() - 1;
 }
+int Dag::dot2(int a, int b, int c, int d) {
+    assert(a >= 0 && b >= 0 && c >= 0 && d >= 0);
+    Node n; n.kind = NK_DOT2; n.a = a; n.b = b; n.c = c; n.d = d;
+    nodes.push_back(n);
+    return (int)nodes.size() - 1;
+}
 int Dag::lin(std::vector<Term> terms) {
     assert(!terms.empty());
     Node n; n.kind = NK_LIN; n.terms = std::move(terms);
@@ -44,6 +50,7 @@ void Dag::store_out(int node, int slot) {
 static void for_each_src(const Node& n, const std::function<void(int)>& f) {
     switch (n.kind) {
         case NK_FMUL: f(n.a); f(n.b); break;
+        case NK_DOT2: f(n.a); f(n.b); f(n.c); f(n.d); break;
         case NK_LIN: for (auto& t : n.terms) f(t.node); break;
         case NK_STOREOUT: f(n.a); break;
         default: break;
@@ -90,6 +97,7 @@ void Dag::optimise() {
         if (!live[i]) continue;
         Node nd = nodes[i];
         if (nd.kind == NK_FMUL) { nd.a = remap[nd.a]; nd.b = remap[nd.b]; }
+        else if (nd.kind == NK_DOT2) { nd.a = remap[nd.a]; nd.b = remap[nd.b]; nd.c = remap[nd.c]; nd.d = remap[nd.d]; }
         else if (nd.kind == NK_STOREOUT) { nd.a = remap[nd.a]; }
         else if (nd.kind == NK_LIN) for (auto& t : nd.terms) t.node = remap[t.node];
         remap[i] = (int)out.size();
@@ -101,9 +109,9 @@ void Dag::optimise() {
 // ------------------------------------------------------------------------------- scheduler
 namespace {
 
-enum OpClass { OC_FMUL = 0, OC_LIN = 1, OC_COPY = 2 };
+enum OpClass { OC_FMUL = 0, OC_LIN = 1, OC_COPY = 2, OC_DOT2 = 3 };
 inline OpClass class_of(NodeKind k) {
-    if (k == NK_FMUL) return OC_FMUL;
+    if (k == NK_FMUL || k == NK_DOT2) return OC_FMUL;  // one multiplier class; see ST_DOT2
     if (k == NK_LIN) return OC_LIN;
     return OC_COPY;
 }
@@ -136,7 +144,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
     // priority = longest weighted path to a sink
     std::vector<int> prio(n, 0);
     for (int i = n - 1; i >= 0; i--) {
-        int w = N[i].kind == NK_FMUL ? 7 : (N[i].kind == NK_LIN ? 2 : 1);
+        int w = N[i].kind == NK_FMUL ? 7 : (N[i].kind == NK_DOT2 ? 9 : (N[i].kind == NK_LIN ? 2 : 1));
         int best = 0;
         for (int s : succ[i]) best = std::max(best, prio[s]);
         prio[i] = best + w;
@@ -154,6 +162,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         for (int s2 : succ[i]) {
             if (N[s2].kind == NK_STOREOUT) target = 1;
             else if (N[s2].kind == NK_FMUL) target = std::min(target, 3);
+            else if (N[s2].kind == NK_DOT2) target = std::min(target, 2);
             else target = std::min(target, 2);
         }
         if (succ[i].empty()) target = 1;
@@ -163,9 +172,12 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         lin_rounds[i] = r; lin_bias[i] = bias;
         bound[i] = std::max(1, total - (1 << r) + 1);
     }
-    for (int i = 0; i < n; i++)
+    for (int i = 0; i < n; i++) {
         if (N[i].kind == NK_FMUL && bound[N[i].a] * bound[N[i].b] > 9)
             throw std::runtime_error("scheduler: FMUL operand bounds too large");
+        if (N[i].kind == NK_DOT2 && bound[N[i].a] * bound[N[i].b] + bound[N[i].c] * bound[N[i].d] > 9)
+            throw std::runtime_error("scheduler: DOT2 operand bounds too large");
+    }
 
     // ---- pass 1: list scheduling into K-wide single-class steps
     const int WINDOW = 600;
@@ -176,9 +188,11 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
     int lo = 0, n_done = 0;
     while (n_done < n) {
         while (lo < n && done[lo]) lo++;
-        std::vector<int> cand[3];
+        std::vector<int> cand[4];
         for (int r : ready) if (r < lo + WINDOW) cand[class_of(N[r].kind)].push_back(r);
         int cls;
+        // full multiplier steps first, then sums and copies (which unlock more multiplications),
+        // then partial multiplier steps
         if ((int)cand[OC_FMUL].size() >= K) cls = OC_FMUL;
         else if (!cand[OC_LIN].empty()) cls = OC_LIN;
         else if (!cand[OC_COPY].empty()) cls = OC_COPY;
@@ -324,7 +338,11 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         // 4. the step itself
         StepHdr h; h.max_terms = 0;
         int step_rounds = 0;
-        h.type = st.cls == OC_FMUL ? ST_FMUL : (st.cls == OC_LIN ? ST_LIN : ST_COPY);
+        bool any_dot2 = false;
+        for (int op : st.ops) any_dot2 |= (N[op].kind == NK_DOT2);
+        // a step holding a two-product op runs the two-product multiplier on every lane; single
+        // products in it use zero for the second product
+        h.type = st.cls == OC_FMUL ? (any_dot2 ? ST_DOT2 : ST_FMUL) : (st.cls == OC_LIN ? ST_LIN : ST_COPY);
         for (int r = 0; r < K; r++) {
             OpDesc d; std::memset(&d, 0, sizeof d);
             if (r < (int)st.ops.size()) {
@@ -335,6 +353,12 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                     case NK_FMUL:
                         d.w[0] = (uint16_t)dst_slot[op]; d.w[1] = (uint16_t)src_slot[nd.a]; d.w[2] = (uint16_t)src_slot[nd.b];
                         P.n_fmul++;
+                        break;
+                    case NK_DOT2:
+                        d.hdr |= 2u;  // second product present
+                        d.w[0] = (uint16_t)dst_slot[op]; d.w[1] = (uint16_t)src_slot[nd.a]; d.w[2] = (uint16_t)src_slot[nd.b];
+                        d.w[3] = (uint16_t)src_slot[nd.c]; d.w[4] = (uint16_t)src_slot[nd.d];
+                        P.n_dot2++;
                         break;
                     case NK_LIN: {
                         int nt = (int)nd.terms.size();
@@ -364,7 +388,8 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         }
         if (st.cls == OC_LIN) h.max_terms |= (uint32_t)step_rounds << 8;  // ladder 2^(r-1) p ... p
         P.hdrs.push_back(h);
-        if (st.cls == OC_FMUL) P.n_fmul_steps++;
+        if (st.cls == OC_FMUL && any_dot2) P.n_dot2_steps++;
+        else if (st.cls == OC_FMUL) P.n_fmul_steps++;
         else if (st.cls == OC_LIN) P.n_lin_steps++;
         else P.n_copy_steps++;
         // values produced but never read (cannot happen after DCE) would leak a slot; guard anyway

@@ -12,7 +12,7 @@
 
 namespace bls381 {
 
-enum NodeKind : uint8_t { NK_FMUL, NK_LIN, NK_LOADIN, NK_LOADC, NK_STOREOUT };
+enum NodeKind : uint8_t { NK_FMUL, NK_LIN, NK_LOADIN, NK_LOADC, NK_STOREOUT, NK_DOT2 };
 
 struct Term {
     int node;
@@ -21,7 +21,8 @@ struct Term {
 
 struct Node {
     NodeKind kind;
-    int a = -1, b = -1;       // FMUL operands; STOREOUT source in a
+    int a = -1, b = -1;       // FMUL / DOT2 operands; STOREOUT source in a
+    int c = -1, d = -1;       // DOT2: a*b + c*d
     int idx = -1;             // LOADIN: gin slot, LOADC: constant id, STOREOUT: gout slot
     std::vector<Term> terms;  // LIN
 };
@@ -34,6 +35,7 @@ class Dag {
     int load_in(int slot);
     int load_const(int cid);
     int fmul(int a, int b);
+    int dot2(int a, int b, int c, int d);
     int lin(std::vector<Term> terms);
     void store_out(int node, int slot);
 
@@ -51,8 +53,8 @@ struct Program {
     std::vector<StepHdr> hdrs;
     std::vector<OpDesc> descs;  // hdrs.size() * K
     // statistics
-    int n_fmul = 0, n_lin = 0, n_lin_terms = 0, n_copy = 0;
-    int n_fmul_steps = 0, n_lin_steps = 0, n_copy_steps = 0;
+    int n_fmul = 0, n_lin = 0, n_lin_terms = 0, n_copy = 0, n_dot2 = 0;
+    int n_fmul_steps = 0, n_lin_steps = 0, n_copy_steps = 0, n_dot2_steps = 0;
 };
 
 // Schedules `dag` for groups of K lanes with at most `lds_slots` LDS slots per group.

@@ -67,12 +67,12 @@ SFq2 Tower::mul(const SFq2& a, const SFq2& b) {
         SFp t01 = mul(a.c0, b.c1), t10 = mul(a.c1, b.c0);
         return {sub(t00, t11), add(t01, t10)};
     }
-    // Karatsuba: 3 products
-    SFp t0 = mul(a.c0, b.c0);
-    SFp t1 = mul(a.c1, b.c1);
-    SFp sa = add(a.c0, a.c1), sb = add(b.c0, b.c1);
-    SFp t2 = mul(sa, sb);
-    return {sub(t0, t1), lin({{t2, 1}, {t0, -1}, {t1, -1}})};
+    // two sums of two products, one reduction each: c0 = a0 b0 + a1 (-b1), c1 = a0 b1 + a1 b0
+    SFp nb1 = neg(b.c1);
+    SFp a0 = mat(a.c0), a1 = mat(a.c1), b0 = mat(b.c0), b1 = mat(b.c1);
+    SFp c0{d_.dot2(a0.id, b0.id, a1.id, nb1.id)};
+    SFp c1{d_.dot2(a0.id, b1.id, a1.id, b0.id)};
+    return {c0, c1};
 }
 
 SFq2 Tower::sqr(const SFq2& a) {

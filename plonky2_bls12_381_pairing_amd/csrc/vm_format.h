@@ -16,6 +16,7 @@ enum StepType : uint32_t {
     ST_FMUL = 0,  // dst = a * b           (Montgomery product, canonical result)
     ST_LIN  = 1,  // dst = sum_i (+/-) t_i (canonical result)
     ST_COPY = 2,  // LDS <-> global slot arrays, constant table -> LDS
+    ST_DOT2 = 3,  // dst = a * b + c * d   (one Montgomery reduction, canonical result)
 };
 
 enum CopyKind : uint32_t {
@@ -34,10 +35,12 @@ struct StepHdr {
 
 // One operation descriptor per (step, lane-in-group).  32 bytes.
 //   hdr bit 0      : active
+//   hdr bit 1      : ST_DOT2: the op has a second product (else dst = a * b)
 //   hdr bits 8..15 : ST_LIN term count / ST_COPY CopyKind
 //   hdr bits 16..23: ST_LIN number of negated terms k; the accumulator starts at k * p
 //   w[0]           : destination slot
 //   ST_FMUL        : w[1] = a, w[2] = b
+//   ST_DOT2        : w[1] = a, w[2] = b, w[3] = c, w[4] = d
 //   ST_LIN         : w[1+i] = slot | (negate << 15), i < term count <= 13
 //   ST_COPY        : w[1] = source slot (LDS slot, global slot or constant id)
 struct OpDesc {

@@ -94,6 +94,21 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                 fp_mul(a, b, r);
                 lds_store(W(0), r);
             }
+        } else if (h.type == ST_DOT2) {
+            if (on) {
+                u32 a[12], b[12], c[12], d[12], r[12];
+                lds_load(W(1), a);
+                lds_load(W(2), b);
+                if (d0.x & 2u) {
+                    lds_load(W(3), c);
+                    lds_load(W(4), d);
+                } else {  // a single product riding in a two-product step
+#pragma unroll
+                    for (int i = 0; i < 12; i++) { c[i] = 0; d[i] = 0; }
+                }
+                fp_dot2(a, b, c, d, r);
+                lds_store(W(0), r);
+            }
         } else if (h.type == ST_LIN) {
             // acc = bias + sum(+/- terms) in 13-limb two's complement; bias = k*p makes it >= 0
             u32 acc[13];

@@ -94,10 +94,11 @@ def test_auxiliary_programs():
 
 
 def test_program_statistics():
+    """Executed 32x32 multiply-accumulates stay at or below the reference work model
+    (7,141 / 8,119 Fp multiplications x 300)."""
     p = S.get_program("miller", 8, 0)
-    # 63 doublings + 5 additions: the multiplication count must stay at or below the reference's model
-    assert 6000 < p["n_fmul"] <= 7141
-    assert S.get_program("fe2", 8, 0)["n_fmul"] <= 8119
+    assert 0.7 * 7141 * 300 < p["n_fmul"] <= 7141 * 300
+    assert S.get_program("fe2", 8, 0)["n_fmul"] <= 8119 * 300
 
 
 def test_witness_program_rows_match_circuit_op_totals():

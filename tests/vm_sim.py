@@ -14,7 +14,7 @@ from plonky2_bls12_381_pairing_amd import _lib
 
 P = R.P
 RINV = pow(1 << 384, -1, P)
-ST_FMUL, ST_LIN, ST_COPY = 0, 1, 2
+ST_FMUL, ST_LIN, ST_COPY, ST_DOT2 = 0, 1, 2, 3
 CK_IN, CK_FILL, CK_CONST, CK_SPILL, CK_OUT = range(5)
 
 
@@ -59,6 +59,12 @@ def run_program(prog, gin, strict=True):
                 assert a is not None and b is not None, "FMUL reads an empty slot"
                 assert a * b < P << 384, "FMUL operands exceed the Montgomery bound"
                 writes.append(("lds", w[0], a * b * RINV % P))
+            elif typ == ST_DOT2:
+                a, b = lds[w[1]], lds[w[2]]
+                c2, d2 = (lds[w[3]], lds[w[4]]) if d[0] & 2 else (0, 0)
+                assert None not in (a, b, c2, d2), "DOT2 reads an empty slot"
+                assert a * b + c2 * d2 < P << 384, "DOT2 operands exceed the Montgomery bound"
+                writes.append(("lds", w[0], (a * b + c2 * d2) * RINV % P))
             elif typ == ST_LIN:
                 nt = (d[0] >> 8) & 0xff
                 kb = (d[0] >> 16) & 0xff
