@@ -29,9 +29,9 @@ int Dag::fmul(int a, int b) {
     nodes.push_back(n);
     return (int)nodes.size() - 1;
 }
-int Dag::dot2(int a, int b, int c, int d) {
+int Dag::dot2(int a, int b, int c, int d, bool neg_d) {
     assert(a >= 0 && b >= 0 && c >= 0 && d >= 0);
-    Node n; n.kind = NK_DOT2; n.a = a; n.b = b; n.c = c; n.d = d;
+    Node n; n.kind = NK_DOT2; n.a = a; n.b = b; n.c = c; n.d = d; n.neg_d = neg_d;
     nodes.push_back(n);
     return (int)nodes.size() - 1;
 }
@@ -243,6 +243,11 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         return p < u.size() ? u[p] : 0x7fffffff;
     };
 
+    // The last two LDS slots are reserved: ZERO always holds 0 (padding operand of idle lanes and
+    // of sums shorter than the step's longest), TRASH receives what idle lanes store.  With them
+    // the multiplier and sum steps need no per-lane branches.
+    const int ZERO_SLOT = lds_slots - 2, TRASH_SLOT = lds_slots - 1;
+    lds_slots -= 2;
     std::vector<int> lds_of(n, -1), tmp_of(n, -1);
     std::vector<int> owner(lds_slots, -1);
     std::vector<int> free_lds;
@@ -345,6 +350,10 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         h.type = st.cls == OC_FMUL ? (any_dot2 ? ST_DOT2 : ST_FMUL) : (st.cls == OC_LIN ? ST_LIN : ST_COPY);
         for (int r = 0; r < K; r++) {
             OpDesc d; std::memset(&d, 0, sizeof d);
+            if (st.cls != OC_COPY) {  // idle lane / padding defaults
+                d.w[0] = (uint16_t)TRASH_SLOT;
+                for (int t = 1; t < 14; t++) d.w[t] = (uint16_t)ZERO_SLOT;
+            }
             if (r < (int)st.ops.size()) {
                 int op = st.ops[r];
                 const Node& nd = N[op];
@@ -356,6 +365,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                         break;
                     case NK_DOT2:
                         d.hdr |= 2u;  // second product present
+                        if (nd.neg_d) d.hdr |= 4u | ((uint32_t)bound[nd.d] << 16);  // subtract it: d -> bound * p - d
                         d.w[0] = (uint16_t)dst_slot[op]; d.w[1] = (uint16_t)src_slot[nd.a]; d.w[2] = (uint16_t)src_slot[nd.b];
                         d.w[3] = (uint16_t)src_slot[nd.c]; d.w[4] = (uint16_t)src_slot[nd.d];
                         P.n_dot2++;
@@ -398,7 +408,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                 int sl = lds_of[op]; owner[sl] = -1; lds_of[op] = -1; free_lds.push_back(sl);
             }
     }
-    P.n_lds_slots = lds_slots;
+    P.n_lds_slots = lds_slots + 2;
     P.n_tmp_slots = n_tmp;
     return P;
 }

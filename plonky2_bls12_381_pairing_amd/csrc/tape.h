@@ -23,6 +23,7 @@ struct Node {
     NodeKind kind;
     int a = -1, b = -1;       // FMUL / DOT2 operands; STOREOUT source in a
     int c = -1, d = -1;       // DOT2: a*b + c*d
+    bool neg_d = false;       // DOT2: a*b - c*d (the kernel forms k*p - d)
     int idx = -1;             // LOADIN: gin slot, LOADC: constant id, STOREOUT: gout slot
     std::vector<Term> terms;  // LIN
 };
@@ -35,7 +36,7 @@ class Dag {
     int load_in(int slot);
     int load_const(int cid);
     int fmul(int a, int b);
-    int dot2(int a, int b, int c, int d);
+    int dot2(int a, int b, int c, int d, bool neg_d = false);
     int lin(std::vector<Term> terms);
     void store_out(int node, int slot);
 

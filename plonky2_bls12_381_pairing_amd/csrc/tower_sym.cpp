@@ -67,10 +67,9 @@ SFq2 Tower::mul(const SFq2& a, const SFq2& b) {
         SFp t01 = mul(a.c0, b.c1), t10 = mul(a.c1, b.c0);
         return {sub(t00, t11), add(t01, t10)};
     }
-    // two sums of two products, one reduction each: c0 = a0 b0 + a1 (-b1), c1 = a0 b1 + a1 b0
-    SFp nb1 = neg(b.c1);
+    // two sums of two products, one reduction each: c0 = a0 b0 - a1 b1, c1 = a0 b1 + a1 b0
     SFp a0 = mat(a.c0), a1 = mat(a.c1), b0 = mat(b.c0), b1 = mat(b.c1);
-    SFp c0{d_.dot2(a0.id, b0.id, a1.id, nb1.id)};
+    SFp c0{d_.dot2(a0.id, b0.id, a1.id, b1.id, /*neg_d=*/true)};
     SFp c1{d_.dot2(a0.id, b1.id, a1.id, b0.id)};
     return {c0, c1};
 }

@@ -36,6 +36,9 @@ struct StepHdr {
 // One operation descriptor per (step, lane-in-group).  32 bytes.
 //   hdr bit 0      : active
 //   hdr bit 1      : ST_DOT2: the op has a second product (else dst = a * b)
+//   hdr bit 2      : ST_DOT2: the second product is subtracted; bits 16..23 = k with d <= k * p
+//   Idle lanes of multiplier and sum steps carry dst = TRASH slot and operands = ZERO slot (the
+//   program's last two LDS slots), so those steps run without per-lane branches.
 //   hdr bits 8..15 : ST_LIN term count / ST_COPY CopyKind
 //   hdr bits 16..23: ST_LIN number of negated terms k; the accumulator starts at k * p
 //   w[0]           : destination slot

@@ -55,6 +55,8 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
 
     // stage the k*p table
     for (int i = tid; i < KP_ROWS * 4; i += VM_THREADS) kp_lds[i] = A.kp[i];
+    // the ZERO slot (second to last) of every group
+    for (int i = tid; i < 3 * GPW; i += VM_THREADS) lds[(size_t)(A.lds_slots - 2) * 3 * GPW + i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
     auto lds_load = [&](int slot, u32* x) {
@@ -86,33 +88,34 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
         const u32 dw[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
         auto W = [&](int i) -> u32 { return (dw[1 + (i >> 1)] >> ((i & 1) * 16)) & 0xffffu; };
 
+        // Multiplier and sum steps are branch-free: idle lanes read the ZERO slot and store to TRASH.
         if (h.type == ST_FMUL) {
-            if (on) {
-                u32 a[12], b[12], r[12];
-                lds_load(W(1), a);
-                lds_load(W(2), b);
-                fp_mul(a, b, r);
-                lds_store(W(0), r);
-            }
+            u32 a[12], b[12], r[12];
+            lds_load(W(1), a);
+            lds_load(W(2), b);
+            fp_mul(a, b, r);
+            lds_store(W(0), r);
         } else if (h.type == ST_DOT2) {
-            if (on) {
-                u32 a[12], b[12], c[12], d[12], r[12];
-                lds_load(W(1), a);
-                lds_load(W(2), b);
-                if (d0.x & 2u) {
-                    lds_load(W(3), c);
-                    lds_load(W(4), d);
-                } else {  // a single product riding in a two-product step
+            u32 a[12], b[12], c[12], d[12], r[12];
+            lds_load(W(1), a);
+            lds_load(W(2), b);
+            lds_load(W(3), c);
+            lds_load(W(4), d);
+            if (d0.x & 4u) {  // a*b - c*d: d <- k*p - d (k*p >= d by the scheduler's bound)
+                const uint4* row = kp_lds + ((d0.x >> 16) & 0xffu) * 4;
+                uint4 r0 = row[0], r1 = row[1], r2 = row[2];
+                u32 q[12];
+                unpack3(r0, r1, r2, q);
+                carry_t cy;
+                d[0] = sub_co(q[0], d[0], cy);
 #pragma unroll
-                    for (int i = 0; i < 12; i++) { c[i] = 0; d[i] = 0; }
-                }
-                fp_dot2(a, b, c, d, r);
-                lds_store(W(0), r);
+                for (int i = 1; i < 12; i++) d[i] = subb_co(q[i], d[i], cy);
             }
+            fp_dot2(a, b, c, d, r);
+            lds_store(W(0), r);
         } else if (h.type == ST_LIN) {
             // acc = bias + sum(+/- terms) in 13-limb two's complement; bias = k*p makes it >= 0
             u32 acc[13];
-            const u32 nterms = (d0.x >> 8) & 0xffu;
             const u32 kb = (d0.x >> 16) & 0xffu;
             {
                 const uint4* row = kp_lds + kb * 4;
@@ -122,18 +125,14 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             }
 #pragma unroll
             for (int t = 0; t < LIN_MAX_TERMS; t++) {
-                if (t < (int)(h.max_terms & 0xffu)) {
-                    if (on && t < (int)nterms) {
-                        const u32 w = W(1 + t);
-                        const u32 m = (w & 0x8000u) ? 0xffffffffu : 0u;
-                        u32 x[12];
-                        lds_load(w & 0x7fffu, x);
-                        // acc += x, or acc += ~x + 1 (two's complement, sign-extended into limb 12)
-                        u32 y[12];
+                if (t < (int)(h.max_terms & 0xffu)) {  // uniform; short sums are padded with +ZERO
+                    const u32 w = W(1 + t);
+                    const u32 m = (w & 0x8000u) ? 0xffffffffu : 0u;
+                    u32 x[12], y[12];
+                    lds_load(w & 0x7fffu, x);
 #pragma unroll
-                        for (int i = 0; i < 12; i++) y[i] = x[i] ^ m;
-                        lin_accumulate(acc, y, m);
-                    }
+                    for (int i = 0; i < 12; i++) y[i] = x[i] ^ m;
+                    lin_accumulate(acc, y, m);  // acc += x, or acc += ~x + 1
                 }
             }
             // conditional subtraction of 2^j * p, j = rounds-1 .. 0
@@ -143,7 +142,7 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             if (rounds > 2) cond_sub_kp<2>(acc);
             if (rounds > 1) cond_sub_kp<1>(acc);
             if (rounds > 0) cond_sub_kp<0>(acc);
-            if (on) lds_store(W(0), acc);
+            lds_store(W(0), acc);
         } else {  // ST_COPY: every lane reads before any lane writes
             const u32 kind = (d0.x >> 8) & 0xffu;
             const u32 dst = W(0), src = W(1);

@@ -41,6 +41,7 @@ def run_program(prog, gin, strict=True):
     K = prog["K"]
     consts = get_constants()
     lds = [None] * prog["lds_slots"]
+    lds[prog["lds_slots"] - 2] = 0            # the ZERO slot; the last slot is TRASH
     gtmp = {}
     gout = [None] * prog["n_out"]
     hd, ds = prog["hdrs"], prog["descs"]
@@ -50,6 +51,9 @@ def run_program(prog, gin, strict=True):
         for r in range(K):
             d = ds[(s * K + r) * 8:(s * K + r) * 8 + 8]
             if not (d[0] & 1):
+                if typ != ST_COPY:  # idle lanes run branch-free on ZERO and store to TRASH
+                    assert d[1] & 0xffff == prog["lds_slots"] - 1
+                    assert all(x == (prog["lds_slots"] - 2) * 0x10001 for x in d[2:]) and d[1] >> 16 == prog["lds_slots"] - 2
                 continue
             w = []
             for x in d[1:]:
@@ -61,8 +65,14 @@ def run_program(prog, gin, strict=True):
                 writes.append(("lds", w[0], a * b * RINV % P))
             elif typ == ST_DOT2:
                 a, b = lds[w[1]], lds[w[2]]
-                c2, d2 = (lds[w[3]], lds[w[4]]) if d[0] & 2 else (0, 0)
+                c2, d2 = lds[w[3]], lds[w[4]]
                 assert None not in (a, b, c2, d2), "DOT2 reads an empty slot"
+                if not d[0] & 2:
+                    assert c2 == 0 and d2 == 0          # single product: padded with ZERO
+                if d[0] & 4:
+                    kd = (d[0] >> 16) & 0xff
+                    assert d2 <= kd * P, "negated operand exceeds its bound"
+                    d2 = kd * P - d2
                 assert a * b + c2 * d2 < P << 384, "DOT2 operands exceed the Montgomery bound"
                 writes.append(("lds", w[0], (a * b + c2 * d2) * RINV % P))
             elif typ == ST_LIN:
@@ -70,8 +80,10 @@ def run_program(prog, gin, strict=True):
                 kb = (d[0] >> 16) & 0xff
                 assert nt <= (mt & 0xff) and kb <= 16
                 acc = kb * P
-                for t in range(nt):
+                for t in range(mt & 0xff):
                     v = lds[w[1 + t] & 0x7fff]
+                    if t >= nt:
+                        assert v == 0 and not w[1 + t] & 0x8000
                     assert v is not None, "LIN reads an empty slot"
                     acc += -v if w[1 + t] & 0x8000 else v
                 assert 0 <= acc < 1 << 416, "13-limb accumulator out of range"
