@@ -128,8 +128,15 @@ int bls381_debug_program(const char* which, int lanes_per_group, int lds_slots, 
  * (out_plain). */
 int bls381_debug_fp_mul(bls381_ctx*, const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out,
                         uint32_t* out_plain);
-/* Constant table (C_COUNT x 12 u32). */
+/* The interpreter's constant table: C_COUNT rows of 16 u32 (14 digits of 28 bits, zero padded). */
 int bls381_debug_constants(uint32_t* out, size_t capacity_fp);
+/* Per-step-kind shader-clock accounting of program `which` ("miller", "fe2", ...) run over n
+ * groups of zero inputs: out[k] cycles and out[16 + k] step counts of the grid's first wave, k = 0
+ * product, 1 sum, 2 sum + carry sweep, 3 two-product, 4.. copies by kind (in, fill, constant, spill,
+ * out), 9 sum + reduction; out[15] = nanoseconds of the same launch repeated without the accounting.
+ * Names starting with "t_" run synthetic single-kind programs ("t_lin4", "t_dot2", "t_spill", ...).
+ * Tuning aid; no counterpart in the reference. */
+int bls381_debug_profile(bls381_ctx*, const char* which, size_t n, uint64_t out[32]);
 /* Timing of the most recent pairing / Miller-loop / final-exponentiation batch call on this context
  * (its last 65,536-element chunk), from HIP events on the context's stream, in milliseconds:
  * ms[0] = Miller-loop kernel, ms[1] = final exponentiation part 1 + Fp inversion kernel,

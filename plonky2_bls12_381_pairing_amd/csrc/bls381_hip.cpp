@@ -33,37 +33,18 @@ static int fail(int code, const std::string& msg) {
 extern "C" const char* bls381_last_error(void) { return g_err.c_str(); }
 
 // ------------------------------------------------------------------ constant tables
+// Boundary-form constants (12 x u32, Montgomery factor 2^384) for the kernels outside the
+// interpreter; only the entry C_ONE is used.
 static void fill_constants(std::vector<uint32_t>& c) {
     c.assign((size_t)C_COUNT * 12, 0);
-    auto put = [&](int id, const uint32_t* v) { std::memcpy(&c[(size_t)id * 12], v, 48); };
-    put(C_ONE, BLS381_ONE_MONT);
-    put(C_TWO_INV, BLS381_TWO_INV_MONT);
-    const uint32_t* f1[5][2] = {{BLS381_FROB1_1_C0, BLS381_FROB1_1_C1}, {BLS381_FROB1_2_C0, BLS381_FROB1_2_C1},
-                                {BLS381_FROB1_3_C0, BLS381_FROB1_3_C1}, {BLS381_FROB1_4_C0, BLS381_FROB1_4_C1},
-                                {BLS381_FROB1_5_C0, BLS381_FROB1_5_C1}};
-    const uint32_t* f2[5] = {BLS381_FROB2_1_C0, BLS381_FROB2_2_C0, BLS381_FROB2_3_C0, BLS381_FROB2_4_C0,
-                             BLS381_FROB2_5_C0};
-    for (int i = 0; i < 5; i++) {
-        put(C_FROB1_BASE + 2 * i, f1[i][0]);
-        put(C_FROB1_BASE + 2 * i + 1, f1[i][1]);
-        put(C_FROB2_BASE + i, f2[i]);
-    }
-    put(C_R2, BLS381_R2);
-    uint32_t one[12] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    put(C_RAW_ONE, one);
+    std::memcpy(&c[(size_t)C_ONE * 12], BLS381_ONE_MONT, 48);
 }
-static void fill_kp(std::vector<uint32_t>& t) {
-    t.assign((size_t)KP_ROWS * 16, 0);
-    for (int k = 1; k < KP_ROWS; k++) {
-        uint64_t c = 0;
-        for (int i = 0; i < 13; i++) {
-            uint64_t s = (uint64_t)t[(size_t)(k - 1) * 16 + i] + BLS381_P1X[i] + c;
-            t[(size_t)k * 16 + i] = (uint32_t)s;
-            c = s >> 32;
-        }
-    }
+// Interpreter constants: C_COUNT rows of 16 u32 (14 digits of 28 bits).
+static void fill_vm_constants(std::vector<uint32_t>& c) {
+    static_assert(sizeof(BLS381_VMCONST28) == (size_t)C_COUNT * 64, "constant table out of step with ConstId");
+    c.assign((size_t)C_COUNT * 16, 0);
+    std::memcpy(c.data(), BLS381_VMCONST28, sizeof(BLS381_VMCONST28));
 }
-
 // ------------------------------------------------------------------ programs
 static Dag build_named(const std::string& which) {
     if (which == "miller") return build_miller();
@@ -84,18 +65,29 @@ static const char* ALL_PROGRAMS[] = {"miller", "g2prep", "ell",  "fe1",     "fe2
                                      "hardgen", "inv1",   "inv2", "fq12mul", "frob1", "frob2"};
 
 static bool valid_k(int K) { return K == 6 || K == 8 || K == 9 || K == 12 || K == 16; }
-static int default_slots(int K) {
-    // 2 workgroups of 256 threads per CU: 160 KiB / 2 minus the k*p table, 48 bytes per slot and group
+static int default_slots(int K) {  // at most MAX_LDS_SLOTS
+    // 2 workgroups of 256 threads per CU: 160 KiB / 2, 56 bytes per slot and group
     int gpw = 4 * (64 / K);
-    int s = (80 * 1024 - KP_ROWS * 64 - 256) / (48 * gpw);
+    int s = (80 * 1024 - 256) / (56 * gpw);
     return std::min(s, 120);
 }
 
 struct DevProgram {
     Program host;
-    StepHdr* d_hdrs = nullptr;
-    OpDesc* d_descs = nullptr;
+    uint4* d_blocks = nullptr;  // packed descriptors, see PackedDesc
+    int nblocks = 0;
 };
+
+// 64 packed descriptors per block: step j of the block, lane-in-group r at index j * K + r
+static std::vector<PackedDesc> pack_blocks(const Program& p) {
+    const int K = p.K, spb = 64 / K, nsteps = (int)p.hdrs.size();
+    const int nblocks = (nsteps + spb - 1) / spb;
+    std::vector<PackedDesc> out((size_t)std::max(1, nblocks) * 64, PackedDesc{{0, 0, 0, 0}});
+    for (int s = 0; s < nsteps; s++)
+        for (int r = 0; r < K; r++)
+            out[(size_t)(s / spb) * 64 + (s % spb) * K + r] = pack_desc(p.hdrs[s], p.descs[(size_t)s * K + r]);
+    return out;
+}
 
 struct DevBuf {
     void* p = nullptr;
@@ -120,7 +112,8 @@ struct bls381_ctx {
     hipStream_t stream = nullptr;
     std::map<std::string, DevProgram> progs;
     uint4* d_consts = nullptr;
-    uint4* d_kp = nullptr;
+    uint4* d_vmconsts = nullptr;
+    unsigned long long* d_prof = nullptr;  // set while bls381_debug_profile runs
     DevBuf user_in, user_in2, user_in3, user_out, flags, bufA, bufB, bufC, bufTmp, zflags;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float last_ms[4] = {0, 0, 0, 0};  // Miller kernel, fe1 + inversion, fe2 kernel, whole device call
@@ -137,19 +130,61 @@ static void program_geometry(const bls381_ctx* c, const std::string& which, int&
     K = c->K; slots = c->lds_slots;
 }
 
+// Synthetic programs for timing one step kind in isolation: 1,000 identical steps with every lane
+// active ("t_lin<n>", "t_sweep<n>", "t_reduce<n>" sums of n terms; "t_mul", "t_dot2"; "t_spill",
+// "t_fill", "t_const").  They compute on whatever the LDS holds; only their duration means anything.
+static Program microbench_program(const std::string& which, int K, int slots) {
+    Program p;
+    p.name = which; p.K = K; p.n_lds_slots = slots; p.n_tmp_slots = K; p.n_in = 0; p.n_out = 0;
+    StepHdr h{ST_COPY, 0};
+    int nterms = 0;
+    uint32_t kind = 0;
+    if (which.rfind("t_lin", 0) == 0) { h.type = ST_LIN; nterms = atoi(which.c_str() + 5); }
+    else if (which.rfind("t_sweep", 0) == 0) { h.type = ST_LIN; nterms = atoi(which.c_str() + 7); h.max_terms = 1u << 8; }
+    else if (which.rfind("t_reduce", 0) == 0) { h.type = ST_LIN; nterms = atoi(which.c_str() + 8); h.max_terms = 2u << 8; }
+    else if (which == "t_mul") h.type = ST_FMUL;
+    else if (which == "t_dot2") h.type = ST_DOT2;
+    else if (which == "t_spill") kind = CK_SPILL;
+    else if (which == "t_fill") kind = CK_FILL;
+    else if (which == "t_const") kind = CK_CONST;
+    else throw std::runtime_error("unknown program " + which);
+    if (nterms < 0 || nterms > LIN_MAX_TERMS || slots < 3 * K + 2) throw std::runtime_error("bad microbenchmark " + which);
+    h.max_terms |= (uint32_t)nterms;
+    for (int s = 0; s < 1000; s++) {
+        p.hdrs.push_back(h);
+        for (int r = 0; r < K; r++) {
+            OpDesc d; std::memset(&d, 0, sizeof d);
+            d.hdr = 1u;
+            if (h.type == ST_COPY) {
+                d.hdr |= kind << 8;
+                d.w[0] = (uint16_t)r; d.w[1] = (uint16_t)(kind == CK_CONST ? r % C_COUNT : r);
+            } else {
+                d.w[0] = (uint16_t)(2 * K + r);
+                for (int t = 0; t < 8; t++) d.w[1 + t] = (uint16_t)((r + 3 * t + s) % (2 * K));
+                if (h.type == ST_DOT2) d.hdr |= 2u | (r & 1 ? 4u : 0u);
+                if (h.type == ST_LIN) { d.hdr |= (uint32_t)nterms << 8; if (nterms > 1) { d.w[2] |= 0x8000; d.hdr |= 1u << 24; } }
+            }
+            p.descs.push_back(d);
+        }
+    }
+    return p;
+}
+
 static int upload_program(bls381_ctx* c, const std::string& which) {
     DevProgram dp;
     try {
         int K, slots;
         program_geometry(c, which, K, slots);
-        dp.host = schedule(build_named(which), K, slots, which);
+        if (which.rfind("t_", 0) == 0) dp.host = microbench_program(which, K, slots);
+        else dp.host = schedule(build_named(which), K, slots, which);
     } catch (std::exception& e) {
         return fail(BLS381_ERR_INVALID, std::string("program ") + which + ": " + e.what());
     }
-    HIPCHK(hipMalloc((void**)&dp.d_hdrs, dp.host.hdrs.size() * sizeof(StepHdr)));
-    HIPCHK(hipMalloc((void**)&dp.d_descs, dp.host.descs.size() * sizeof(OpDesc)));
-    HIPCHK(hipMemcpy(dp.d_hdrs, dp.host.hdrs.data(), dp.host.hdrs.size() * sizeof(StepHdr), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dp.d_descs, dp.host.descs.data(), dp.host.descs.size() * sizeof(OpDesc), hipMemcpyHostToDevice));
+    if (dp.host.n_lds_slots > MAX_LDS_SLOTS) return fail(BLS381_ERR_INVALID, "more LDS slots than a descriptor can address");
+    std::vector<PackedDesc> blocks = pack_blocks(dp.host);
+    dp.nblocks = (int)(blocks.size() / 64);
+    HIPCHK(hipMalloc((void**)&dp.d_blocks, blocks.size() * sizeof(PackedDesc)));
+    HIPCHK(hipMemcpy(dp.d_blocks, blocks.data(), blocks.size() * sizeof(PackedDesc), hipMemcpyHostToDevice));
     c->progs[which] = dp;
     return 0;
 }
@@ -170,7 +205,7 @@ extern "C" int bls381_ctx_create_ex(bls381_ctx** out, int device_id, int K, int 
     HIPCHK(hipGetDeviceProperties(&prop, device_id));
     if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
         return fail(BLS381_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950");
-    size_t lds_bytes = (size_t)lds_slots * 48 * (4 * (64 / K)) + KP_ROWS * 64;
+    size_t lds_bytes = vm_lds_bytes(lds_slots, K);
     if (lds_bytes > 160 * 1024) return fail(BLS381_ERR_INVALID, "lds_slots does not fit the 160 KiB LDS");
     bls381_ctx* c = new bls381_ctx();
     c->device = device_id; c->K = K; c->lds_slots = lds_slots; c->auto_geometry = auto_geometry;
@@ -178,13 +213,13 @@ extern "C" int bls381_ctx_create_ex(bls381_ctx** out, int device_id, int K, int 
     auto bail = [&](int code) { bls381_ctx_destroy(c); return code; };
     if (hipStreamCreate(&c->stream) != hipSuccess) return bail(fail(BLS381_ERR_HIP, "hipStreamCreate failed"));
     for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) return bail(fail(BLS381_ERR_HIP, "hipEventCreate failed"));
-    std::vector<uint32_t> consts, kp;
+    std::vector<uint32_t> consts, vmc;
     fill_constants(consts);
-    fill_kp(kp);
+    fill_vm_constants(vmc);
     if (hipMalloc((void**)&c->d_consts, consts.size() * 4) != hipSuccess ||
-        hipMalloc((void**)&c->d_kp, kp.size() * 4) != hipSuccess ||
+        hipMalloc((void**)&c->d_vmconsts, vmc.size() * 4) != hipSuccess ||
         hipMemcpy(c->d_consts, consts.data(), consts.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c->d_kp, kp.data(), kp.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+        hipMemcpy(c->d_vmconsts, vmc.data(), vmc.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(BLS381_ERR_HIP, "constant upload failed"));
     for (const char* nm : ALL_PROGRAMS) {
         rc = upload_program(c, nm);
@@ -198,13 +233,13 @@ extern "C" int bls381_ctx_create(bls381_ctx** out, int device_id) { return bls38
 extern "C" void bls381_ctx_destroy(bls381_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (auto& kv : c->progs) { (void)hipFree(kv.second.d_hdrs); (void)hipFree(kv.second.d_descs); }
+    for (auto& kv : c->progs) (void)hipFree(kv.second.d_blocks);
     for (DevBuf* b : {&c->user_in, &c->user_in2, &c->user_in3, &c->user_out, &c->flags, &c->bufA, &c->bufB, &c->bufC,
                       &c->bufTmp, &c->zflags})
         b->release();
     c->wit.release();
     if (c->d_consts) (void)hipFree(c->d_consts);
-    if (c->d_kp) (void)hipFree(c->d_kp);
+    if (c->d_vmconsts) (void)hipFree(c->d_vmconsts);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -219,9 +254,11 @@ static hipError_t launch_vm_kt(bls381_ctx* c, const DevProgram& p, const uint4* 
                                int npad) {
     constexpr int GPW = 4 * (64 / K);
     VmArgs a;
-    a.hdrs = p.d_hdrs; a.descs = p.d_descs; a.nsteps = (int)p.host.hdrs.size(); a.lds_slots = p.host.n_lds_slots;
-    a.consts = c->d_consts; a.kp = c->d_kp; a.gin = gin; a.gout = gout; a.gtmp = gtmp; a.n = n; a.npad = npad;
-    size_t lds = (size_t)p.host.n_lds_slots * 48 * GPW + KP_ROWS * 64;
+    a.blocks = p.d_blocks; a.nblocks = p.nblocks; a.nsteps = (int)p.host.hdrs.size(); a.lds_slots = p.host.n_lds_slots;
+    a.prof = c->d_prof; a.consts = c->d_vmconsts; a.gin = gin; a.gout = gout; a.gtmp = gtmp; a.n = n; a.npad = npad;
+    // the spill array's 8-byte tails follow its 48-byte parts
+    a.gtmp_tail = reinterpret_cast<uint2*>(gtmp + (size_t)std::max(1, p.host.n_tmp_slots) * 3 * npad);
+    size_t lds = vm_lds_bytes(p.host.n_lds_slots, K);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)vm_kernel<K, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -235,6 +272,7 @@ static hipError_t launch_vm_kt(bls381_ctx* c, const DevProgram& p, const uint4* 
 template <int K>
 static hipError_t launch_vm_k(bls381_ctx* c, const DevProgram& p, const uint4* gin, uint4* gout, uint4* gtmp, int n,
                               int npad) {
+    if (c->d_prof) return launch_vm_kt<K, TAG_PROFILE>(c, p, gin, gout, gtmp, n, npad);
     if (p.host.name == "miller") return launch_vm_kt<K, TAG_MILLER>(c, p, gin, gout, gtmp, n, npad);
     if (p.host.name == "fe2") return launch_vm_kt<K, TAG_FINAL_EXP>(c, p, gin, gout, gtmp, n, npad);
     return launch_vm_kt<K, TAG_AUX>(c, p, gin, gout, gtmp, n, npad);
@@ -244,7 +282,7 @@ static int run_program(bls381_ctx* c, const char* which, const void* gin, void* 
     auto it = c->progs.find(which);
     if (it == c->progs.end()) return fail(BLS381_ERR_INVALID, std::string("no program ") + which);
     const DevProgram& p = it->second;
-    HIPCHK(c->bufTmp.ensure(soa_bytes(std::max(1, p.host.n_tmp_slots), npad)));
+    HIPCHK(c->bufTmp.ensure((size_t)std::max(1, p.host.n_tmp_slots) * 56 * npad));
     hipError_t e;
     switch (p.host.K) {
         case 6: e = launch_vm_k<6>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)c->bufTmp.p, n, npad); break;
@@ -719,6 +757,10 @@ extern "C" int bls381_debug_program(const char* which, int K, int lds_slots, uin
     }
     info[0] = K; info[1] = (uint32_t)p.hdrs.size(); info[2] = p.n_lds_slots; info[3] = p.n_tmp_slots;
     info[4] = p.n_in; info[5] = p.n_out; info[6] = p.n_fmul * 300 + p.n_dot2 * 444; info[7] = p.n_lin;
+    if (getenv("BLS381_SCHED_STATS"))
+        fprintf(stderr, "%s K=%d slots=%d: steps %zu (mul %d, dot2 %d, sum %d, copy %d) ops: mul %d dot2 %d sum %d (terms %d, reducing %d, sweeping %d) copy %d tmp %d\n",
+                which, K, lds_slots, p.hdrs.size(), p.n_fmul_steps, p.n_dot2_steps, p.n_lin_steps, p.n_copy_steps, p.n_fmul,
+                p.n_dot2, p.n_lin, p.n_lin_terms, p.n_reduce, p.n_norm, p.n_copy, p.n_tmp_slots);
     if (hdrs && descs) {
         if (capacity_steps < p.hdrs.size()) return fail(BLS381_ERR_INVALID, "capacity too small");
         std::memcpy(hdrs, p.hdrs.data(), p.hdrs.size() * sizeof(StepHdr));
@@ -729,7 +771,7 @@ extern "C" int bls381_debug_program(const char* which, int K, int lds_slots, uin
 extern "C" int bls381_debug_constants(uint32_t* out, size_t capacity_fp) {
     if (!out || capacity_fp < C_COUNT) return fail(BLS381_ERR_INVALID, "buffer too small");
     std::vector<uint32_t> c;
-    fill_constants(c);
+    fill_vm_constants(c);
     std::memcpy(out, c.data(), c.size() * 4);
     return 0;
 }
@@ -784,6 +826,44 @@ __global__ void mac_rate_kernel(u32* out, u32 seed, int iters) {
     for (int i = 0; i < 8; i++) s += acc[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = (u32)s ^ (u32)(s >> 32);
 }
+// Runs program `which` over n groups of zero-filled inputs with per-step-kind cycle accounting
+// (see TAG_PROFILE).  out[0..16) cycles, out[16..32) step counts, both for the first wave only.
+extern "C" int bls381_debug_profile(bls381_ctx* c, const char* which, size_t n, uint64_t out[32]) {
+    CTX_GUARD(c);
+    if (!which || !out || n == 0 || n > CHUNK) return fail(BLS381_ERR_INVALID, "bad argument");
+    if (c->progs.find(which) == c->progs.end() && std::string(which).rfind("t_", 0) == 0) {
+        int rc0 = upload_program(c, which);
+        if (rc0) return rc0;
+    }
+    auto it = c->progs.find(which);
+    if (it == c->progs.end()) return fail(BLS381_ERR_INVALID, std::string("no program ") + which);
+    int npad = pad_elems(n);
+    HIPCHK(c->bufA.ensure(soa_bytes(std::max(1, it->second.host.n_in), npad)));
+    HIPCHK(c->bufB.ensure(soa_bytes(std::max(1, it->second.host.n_out), npad)));
+    HIPCHK(hipMemsetAsync(c->bufA.p, 0, soa_bytes(std::max(1, it->second.host.n_in), npad), c->stream));
+    unsigned long long* prof = nullptr;
+    HIPCHK(hipMalloc((void**)&prof, 32 * 8));
+    int rc = 0;
+    if (hipMemsetAsync(prof, 0, 32 * 8, c->stream) != hipSuccess) rc = fail(BLS381_ERR_HIP, "memset failed");
+    c->d_prof = prof;
+    if (!rc) rc = run_program(c, which, c->bufA.p, c->bufB.p, (int)n, npad);
+    c->d_prof = nullptr;
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(BLS381_ERR_HIP, "profile run failed");
+    if (!rc && hipMemcpy(out, prof, 32 * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(BLS381_ERR_HIP, "copy failed");
+    // the same launch without the accounting, timed: out[15] = nanoseconds
+    if (!rc) {
+        float ms = 0;
+        if (hipEventRecord(c->ev[0], c->stream) != hipSuccess) rc = fail(BLS381_ERR_HIP, "event failed");
+        if (!rc) rc = run_program(c, which, c->bufA.p, c->bufB.p, (int)n, npad);
+        if (!rc && (hipEventRecord(c->ev[1], c->stream) != hipSuccess || hipEventSynchronize(c->ev[1]) != hipSuccess ||
+                    hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) != hipSuccess))
+            rc = fail(BLS381_ERR_HIP, "timing failed");
+        out[15] = (uint64_t)(ms * 1e6);
+    }
+    (void)hipFree(prof);
+    return rc;
+}
+
 extern "C" int bls381_calibrate_mac_rate(bls381_ctx* c, double* mac_per_s) {
     CTX_GUARD(c);
     if (!mac_per_s) return fail(BLS381_ERR_INVALID, "NULL argument");

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cassert>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -150,34 +151,78 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         prio[i] = best + w;
     }
 
-    // ---- bound analysis: a LIN result may stay unreduced (value <= bound * p) when every consumer
-    // tolerates it.  FMUL needs bound(a) * bound(b) * p^2 < p * 2^384, i.e. the product of bounds <= 9;
-    // stores need a canonical value; 12 limbs hold at most 9p.
-    std::vector<int> bound(n, 1), lin_rounds(n, 0), lin_bias(n, 0);
-    for (int i = 0; i < n; i++) {
-        if (N[i].kind != NK_LIN) continue;
-        int total = 0, bias = 0;
-        for (auto& t : N[i].terms) { total += bound[t.node]; if (t.neg) bias += bound[t.node]; }
-        int target = 9;
-        for (int s2 : succ[i]) {
-            if (N[s2].kind == NK_STOREOUT) target = 1;
-            else if (N[s2].kind == NK_FMUL) target = std::min(target, 3);
-            else if (N[s2].kind == NK_DOT2) target = std::min(target, 2);
-            else target = std::min(target, 2);
+    // ---- bound analysis.  Values are lazily reduced signed-digit numbers:
+    //   |value| < vb * p                 (value bound)
+    //   |digit| <= db * 2^28             (digit bound; the top digit follows from vb)
+    //   product / two-product sum: needs  sum of vb products <= 2500  (2^392 / p = 2520.2)
+    //                              and    sum of db products <= 8     (64-bit column accumulator);
+    //                              result vb = 2, db = 1
+    //   sum:                       vb and db add up; db <= 7 (32-bit digits)
+    //   sum + carry sweep:         db = 1
+    //   sum + sweep + reduction:   vb = 2, db = 1
+    // A sum gets a sweep or a reduction only when a consumer's limit demands it.
+    const int MUL_VB_LIMIT = 2500, MUL_DB_LIMIT = 8, SUM_VB_LIMIT = 2047, SUM_DB_LIMIT = 7;
+    std::vector<int> vb(n, 1), db(n, 1);
+    std::vector<char> lin_norm(n, 0), lin_reduce(n, 0);
+    int n_reduce = 0, n_norm = 0;
+    // picks the sum among `cands` with the largest bound that has not been treated yet
+    auto widest = [&](const std::vector<int>& cands, const std::vector<int>& bnd, const std::vector<char>& done_flag) {
+        int best = -1;
+        for (int x : cands)
+            if (N[x].kind == NK_LIN && !done_flag[x] && !lin_reduce[x] && (best < 0 || bnd[x] > bnd[best])) best = x;
+        if (best < 0) throw std::runtime_error("scheduler: operand bounds cannot be met (" + name + ")");
+        return best;
+    };
+    // Sums with several consumers are treated eagerly once their bounds pass a threshold: one sweep
+    // or reduction there spares each consumer (and their consumers) its own.
+    auto env_int = [](const char* nm, int dflt) { const char* v = getenv(nm); return v ? atoi(v) : dflt; };
+    const int VB_EAGER = env_int("BLS381_VB_EAGER", 12), DB_EAGER = env_int("BLS381_DB_EAGER", 3);
+    for (bool again = true; again;) {
+        again = false;
+        for (int i = 0; i < n && !again; i++) {
+            const Node& nd = N[i];
+            switch (nd.kind) {
+                case NK_LOADIN: vb[i] = 10; db[i] = 1; break;  // any 384-bit pattern is below 10p
+                case NK_LOADC: vb[i] = 1; db[i] = 1; break;
+                case NK_FMUL:
+                case NK_DOT2: {
+                    std::vector<int> ops{nd.a, nd.b};
+                    int sv = vb[nd.a] * vb[nd.b], sd = db[nd.a] * db[nd.b];
+                    if (nd.kind == NK_DOT2) {
+                        ops.push_back(nd.c); ops.push_back(nd.d);
+                        sv += vb[nd.c] * vb[nd.d]; sd += db[nd.c] * db[nd.d];
+                    }
+                    if (sv > MUL_VB_LIMIT) { int x = widest(ops, vb, lin_reduce); lin_reduce[x] = 1; n_reduce++; again = true; }
+                    else if (sd > MUL_DB_LIMIT) { int x = widest(ops, db, lin_norm); lin_norm[x] = 1; n_norm++; again = true; }
+                    vb[i] = 2; db[i] = 1;
+                    break;
+                }
+                case NK_LIN: {
+                    int sv = 0, sd = 0;
+                    std::vector<int> ops;
+                    for (auto& t : nd.terms) { sv += vb[t.node]; sd += db[t.node]; ops.push_back(t.node); }
+                    if (sv > SUM_VB_LIMIT) { int x = widest(ops, vb, lin_reduce); lin_reduce[x] = 1; n_reduce++; again = true; }
+                    else if (sd > SUM_DB_LIMIT) { int x = widest(ops, db, lin_norm); lin_norm[x] = 1; n_norm++; again = true; }
+                    else if (succ[i].size() >= 2) {
+                        if (sv >= VB_EAGER && !lin_reduce[i]) { lin_reduce[i] = 1; n_reduce++; }
+                        else if (sd >= DB_EAGER && !lin_norm[i] && !lin_reduce[i]) { lin_norm[i] = 1; n_norm++; }
+                    }
+                    vb[i] = lin_reduce[i] ? 2 : sv;
+                    db[i] = (lin_reduce[i] || lin_norm[i]) ? 1 : sd;
+                    break;
+                }
+                case NK_STOREOUT:
+                    // a store handles (-p, 2p) with normalised digits: what multiplications produce
+                    if (N[nd.a].kind != NK_FMUL && N[nd.a].kind != NK_DOT2)
+                        throw std::runtime_error("scheduler: stored value must come from a multiplication");
+                    break;
+            }
         }
-        if (succ[i].empty()) target = 1;
-        int r = 0;
-        while (std::max(1, total - (1 << r) + 1) > target) r++;
-        if (bias > 16 || total > 31 || r > 5) throw std::runtime_error("scheduler: LIN bound out of range");
-        lin_rounds[i] = r; lin_bias[i] = bias;
-        bound[i] = std::max(1, total - (1 << r) + 1);
     }
-    for (int i = 0; i < n; i++) {
-        if (N[i].kind == NK_FMUL && bound[N[i].a] * bound[N[i].b] > 9)
-            throw std::runtime_error("scheduler: FMUL operand bounds too large");
-        if (N[i].kind == NK_DOT2 && bound[N[i].a] * bound[N[i].b] + bound[N[i].c] * bound[N[i].d] > 9)
-            throw std::runtime_error("scheduler: DOT2 operand bounds too large");
-    }
+    n_norm = 0;
+    for (int i = 0; i < n; i++) if (lin_norm[i] && lin_reduce[i]) lin_norm[i] = 0;  // a reduction sweeps anyway
+    for (int i = 0; i < n; i++) n_norm += lin_norm[i];
+    P.n_reduce = n_reduce; P.n_norm = n_norm;
 
     // ---- pass 1: list scheduling into K-wide single-class steps
     const int WINDOW = 600;
@@ -207,12 +252,27 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
             if (cls == OC_LIN) {
                 // keep the most urgent op, fill the step with the ops closest to it in cost
                 int lead = c[0];
-                auto cost = [&](int x) { return (int)N[x].terms.size() * 34 + lin_rounds[x] * 29; };
+                auto cost = [&](int x) { return (int)N[x].terms.size() * 20 + lin_norm[x] * 40 + lin_reduce[x] * 100; };
                 std::stable_sort(c.begin() + 1, c.end(), [&](int a, int b) {
                     return std::abs(cost(a) - cost(lead)) < std::abs(cost(b) - cost(lead));
                 });
             }
-            c.resize(K);
+        }
+        {
+            // at most K ops whose distinct operands and results all fit the group's LDS slots at once
+            const size_t budget = (size_t)std::max(8, lds_slots - 2 - 2);
+            std::set<int> touched;
+            std::vector<int> kept;
+            for (int x : c) {
+                if ((int)kept.size() == K) break;
+                std::set<int> t2 = touched;
+                for_each_src(N[x], [&](int s2) { t2.insert(s2); });
+                if (N[x].kind != NK_STOREOUT) t2.insert(x);
+                if (t2.size() > budget && !kept.empty()) continue;
+                touched.swap(t2);
+                kept.push_back(x);
+            }
+            c.swap(kept);
         }
         RawStep st; st.cls = (OpClass)cls; st.ops = c;
         std::set<int> chosen(c.begin(), c.end());
@@ -365,7 +425,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                         break;
                     case NK_DOT2:
                         d.hdr |= 2u;  // second product present
-                        if (nd.neg_d) d.hdr |= 4u | ((uint32_t)bound[nd.d] << 16);  // subtract it: d -> bound * p - d
+                        if (nd.neg_d) d.hdr |= 4u;  // subtract it
                         d.w[0] = (uint16_t)dst_slot[op]; d.w[1] = (uint16_t)src_slot[nd.a]; d.w[2] = (uint16_t)src_slot[nd.b];
                         d.w[3] = (uint16_t)src_slot[nd.c]; d.w[4] = (uint16_t)src_slot[nd.d];
                         P.n_dot2++;
@@ -377,9 +437,11 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                         d.w[0] = (uint16_t)dst_slot[op];
                         for (int t = 0; t < nt; t++)
                             d.w[1 + t] = (uint16_t)(src_slot[nd.terms[t].node] | (nd.terms[t].neg ? 0x8000 : 0));
-                        d.hdr |= (uint32_t)lin_bias[op] << 16;  // acc starts at bias * p >= sum of negated terms
+                        int nneg = 0;
+                        for (auto& t : nd.terms) nneg += t.neg;
+                        d.hdr |= (uint32_t)nneg << 24;
                         h.max_terms = std::max<uint32_t>(h.max_terms, nt);
-                        step_rounds = std::max(step_rounds, lin_rounds[op]);
+                        step_rounds |= (lin_reduce[op] ? 2 : 0) | (lin_norm[op] ? 1 : 0);
                         P.n_lin++; P.n_lin_terms += nt;
                         break;
                     }
@@ -396,7 +458,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
             }
             P.descs.push_back(d);
         }
-        if (st.cls == OC_LIN) h.max_terms |= (uint32_t)step_rounds << 8;  // ladder 2^(r-1) p ... p
+        if (st.cls == OC_LIN) h.max_terms |= (uint32_t)step_rounds << 8;  // carry sweep / reduction wanted by some op
         P.hdrs.push_back(h);
         if (st.cls == OC_FMUL && any_dot2) P.n_dot2_steps++;
         else if (st.cls == OC_FMUL) P.n_fmul_steps++;

@@ -37,16 +37,19 @@ SFp Tower::mul(SFp a, SFp b) {
     return SFp{d_.fmul(a.id, b.id)};
 }
 
-void Tower::out(SFp a, int slot) {
-    SFp m = a;
+static int materialise_for_store(Dag& d, Tower& T, SFp a) {
     if (a.is_zero()) {
         // 0 = 1 - 1 keeps the store path uniform
-        SFp one = cst(C_ONE);
-        m = SFp{d_.lin({Term{one.id, false}, Term{one.id, true}})};
-    } else {
-        m = mat(a);
+        SFp one = T.cst(C_ONE);
+        return d.lin({Term{one.id, false}, Term{one.id, true}});
     }
-    d_.store_out(m.id, slot);
+    return a.is_one() ? T.cst(C_ONE).id : a.id;
+}
+void Tower::out(SFp a, int slot) {
+    d_.store_out(d_.fmul(materialise_for_store(d_, *this, a), d_.load_const(C_OUT)), slot);
+}
+void Tower::out_canon(SFp a, int slot) {
+    d_.store_out(d_.fmul(materialise_for_store(d_, *this, a), d_.load_const(C_OUT_CANON)), slot);
 }
 
 // ------------------------------------------------------------------ Fq2
@@ -317,12 +320,10 @@ void Tower::out12(const SFq12& a, int base) {
 static void miller_body(Tower& T, SFq12& f, bool emit_coeffs, int q_base, int p_base) {
     Dag& d = T.dag();
     (void)d;
-    auto load_q = [&](SFq2& qx, SFq2& qy) {
-        qx = SFq2{T.in(q_base + 0), T.in(q_base + 1)};
-        qy = SFq2{T.in(q_base + 2), T.in(q_base + 3)};
-    };
-    SFq2 qx, qy;
-    load_q(qx, qy);
+    // each input is converted once (a multiplication) and then lives like any other value
+    const SFq2 qx{T.in(q_base + 0), T.in(q_base + 1)}, qy{T.in(q_base + 2), T.in(q_base + 3)};
+    SFp px = SZERO, py = SZERO;
+    if (!emit_coeffs) { px = T.in(p_base + 0); py = T.in(p_base + 1); }
     Tower::G2Proj r{qx, qy, T.one2()};
     int k = 0;
     for (int i = 62; i >= 0; i--) {
@@ -334,19 +335,17 @@ static void miller_body(Tower& T, SFq12& f, bool emit_coeffs, int q_base, int p_
             T.out(c.c2.c0, 6 * k + 4); T.out(c.c2.c1, 6 * k + 5);
         } else {
             f = T.sqr(f);
-            f = T.ell(f, c, T.in(p_base + 0), T.in(p_base + 1));
+            f = T.ell(f, c, px, py);
         }
         k++;
         if ((BLS381_X >> i) & 1) {
-            SFq2 ax, ay;
-            load_q(ax, ay);  // reloaded at each use: short live ranges
-            c = T.g2_add(r, ax, ay);
+            c = T.g2_add(r, qx, qy);
             if (emit_coeffs) {
                 T.out(c.c0.c0, 6 * k + 0); T.out(c.c0.c1, 6 * k + 1);
                 T.out(c.c1.c0, 6 * k + 2); T.out(c.c1.c1, 6 * k + 3);
                 T.out(c.c2.c0, 6 * k + 4); T.out(c.c2.c1, 6 * k + 5);
             } else {
-                f = T.ell(f, c, T.in(p_base + 0), T.in(p_base + 1));
+                f = T.ell(f, c, px, py);
             }
             k++;
         }
@@ -464,9 +463,8 @@ Dag build_fq12_inv_limbs_part1() {
     Dag d;
     d.n_in = 12; d.n_out = FE_CARRY;
     Tower T(d);
-    // canonical -> Montgomery: multiply by R^2
     SFp v[12];
-    for (int k = 0; k < 12; k++) v[MY_TO_ARK[k]] = T.mul(T.in(k), T.cst(C_R2));
+    for (int k = 0; k < 12; k++) v[MY_TO_ARK[k]] = T.in_canon(k);
     SFq12 a{{{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}}, {{v[6], v[7]}, {v[8], v[9]}, {v[10], v[11]}}};
     Tower::InvCarry c = T.inv_part1(a);
     store_carry(T, a, c);
@@ -481,8 +479,7 @@ Dag build_fq12_inv_limbs_part2() {
     SFq12 r = load_carry_inverse(T, a);
     const SFp v[12] = {r.c0.c0.c0, r.c0.c0.c1, r.c0.c1.c0, r.c0.c1.c1, r.c0.c2.c0, r.c0.c2.c1,
                        r.c1.c0.c0, r.c1.c0.c1, r.c1.c1.c0, r.c1.c1.c1, r.c1.c2.c0, r.c1.c2.c1};
-    // Montgomery -> canonical: multiply by the integer 1
-    for (int k = 0; k < 12; k++) T.out(T.mul(v[MY_TO_ARK[k]], T.cst(C_RAW_ONE)), k);
+    for (int k = 0; k < 12; k++) T.out_canon(v[MY_TO_ARK[k]], k);
     d.optimise();
     return d;
 }

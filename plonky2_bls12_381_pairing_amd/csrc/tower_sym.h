@@ -38,7 +38,12 @@ class Tower {
     SFp neg(SFp a) { return lin({{a, -1}}); }
     SFp mul(SFp a, SFp b);
     SFp cst(int cid) { return SFp{d_.load_const(cid)}; }
-    SFp in(int slot) { return SFp{d_.load_in(slot)}; }
+    // Boundary values are 12 x u32 with Montgomery factor 2^384 (or canonical integers for the
+    // *_canon pair); inside a program values carry the factor 2^392.  One multiplication by a
+    // constant changes the factor on the way in and on the way out.
+    SFp in(int slot) { return SFp{d_.fmul(d_.load_in(slot), d_.load_const(C_IN))}; }
+    SFp in_canon(int slot) { return SFp{d_.fmul(d_.load_in(slot), d_.load_const(C_IN_CANON))}; }
+    void out_canon(SFp a, int slot);
     void out(SFp a, int slot);
 
     // ---- Fq2

@@ -4,28 +4,33 @@
 
 #include "fp_dev.h"
 #include "fp_asm_gen.h"
+#include "fp28_dev.h"
 #include "vm_format.h"
 
 namespace bls381 {
 
-// Global slot arrays are structure-of-arrays: slot s, 16-byte chunk c (3 per Fp), element e:
+// Global slot arrays (gin, gout: boundary form, 12 x u32 per value) are structure-of-arrays:
+// slot s, 16-byte chunk c (3 per Fp), element e:
 //   uint4 index = (s * 3 + c) * npad + e          -> a wave reads 64 consecutive uint4
-// LDS slots use the same shape with the workgroup's group count in place of npad.
+// The spill array holds interpreter values (14 digits): the same three chunks plus an 8-byte tail,
+//   uint2 index = s * npad + e   in a second region.
+// LDS slots use the spill array's shape with the workgroup's group count in place of npad.
 struct VmArgs {
-    const StepHdr* hdrs;
-    const OpDesc* descs;
+    const uint4* blocks;  // packed descriptors, 64 per block (see PackedDesc)
+    int nblocks;
     int nsteps;
     int lds_slots;
-    const uint4* consts;  // C_COUNT * 3 uint4
-    const uint4* kp;      // 17 rows of 4 uint4: k * p as 13 limbs (zero padded), k = 0..16
+    const uint4* consts;  // C_COUNT rows of 4 uint4: 14 digits, zero padded
     const uint4* gin;
     uint4* gout;
     uint4* gtmp;
+    uint2* gtmp_tail;
     int n;     // number of groups (pairings) with work
     int npad;  // element stride of the global slot arrays
+    unsigned long long* prof;  // TAG_PROFILE only: [0..16) cycles per step kind, [16..32) step counts
 };
 
-enum { VM_THREADS = 256, KP_ROWS = 17 };
+enum { VM_THREADS = 256 };
 
 __device__ __forceinline__ void unpack3(const uint4& a, const uint4& b, const uint4& c, u32* x) {
     x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
@@ -33,16 +38,24 @@ __device__ __forceinline__ void unpack3(const uint4& a, const uint4& b, const ui
     x[8] = c.x; x[9] = c.y; x[10] = c.z; x[11] = c.w;
 }
 
+// LDS bytes a workgroup of the interpreter needs
+__host__ __device__ inline size_t vm_lds_bytes(int lds_slots, int K) {
+    const int gpw = 4 * (64 / K);
+    return (size_t)lds_slots * gpw * 56;
+}
+
 // TAG only gives the Miller-loop, final-exponentiation and auxiliary launches distinct kernel
-// names in profiler output; the code is identical.
-enum { TAG_MILLER = 0, TAG_FINAL_EXP = 1, TAG_AUX = 2 };
+// names in profiler output; the code is identical.  TAG_PROFILE additionally has the first lane of
+// the grid add the shader-clock cycles of every step to A.prof, by step kind: 0 product, 1 sum,
+// 2 sum + carry sweep, 3 two-product, 4 + CopyKind copies, 9 sum + reduction.
+enum { TAG_MILLER = 0, TAG_FINAL_EXP = 1, TAG_AUX = 2, TAG_PROFILE = 3 };
 
 template <int K, int TAG>
 __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
     constexpr int G = 64 / K;      // groups per wave
     constexpr int GPW = 4 * G;     // groups per workgroup
     extern __shared__ uint4 lds[];
-    uint4* kp_lds = lds + (size_t)A.lds_slots * 3 * GPW;
+    uint2* lds_tail = reinterpret_cast<uint2*>(lds + (size_t)A.lds_slots * 3 * GPW);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -53,124 +66,164 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
     const long e = (long)blockIdx.x * GPW + g;
     const bool lane_on = (role_raw < K) && (e < A.n);
 
-    // stage the k*p table
-    for (int i = tid; i < KP_ROWS * 4; i += VM_THREADS) kp_lds[i] = A.kp[i];
     // the ZERO slot (second to last) of every group
     for (int i = tid; i < 3 * GPW; i += VM_THREADS) lds[(size_t)(A.lds_slots - 2) * 3 * GPW + i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < GPW; i += VM_THREADS) lds_tail[(size_t)(A.lds_slots - 2) * GPW + i] = make_uint2(0, 0);
     __syncthreads();
 
     auto lds_load = [&](int slot, u32* x) {
         const uint4* p = lds + (size_t)slot * 3 * GPW + g;
         uint4 a = p[0], b = p[GPW], c = p[2 * GPW];
+        uint2 t = lds_tail[(size_t)slot * GPW + g];
         unpack3(a, b, c, x);
+        x[12] = t.x; x[13] = t.y;
     };
     auto lds_store = [&](int slot, const u32* x) {
         uint4* p = lds + (size_t)slot * 3 * GPW + g;
         p[0] = make_uint4(x[0], x[1], x[2], x[3]);
         p[GPW] = make_uint4(x[4], x[5], x[6], x[7]);
         p[2 * GPW] = make_uint4(x[8], x[9], x[10], x[11]);
+        lds_tail[(size_t)slot * GPW + g] = make_uint2(x[12], x[13]);
     };
-
-    const uint4* dptr = reinterpret_cast<const uint4*>(A.descs) + (size_t)role * 2;
-    uint4 nd0 = dptr[0], nd1 = dptr[1];
-
-    StepHdr nh = A.hdrs[0];
-    for (int s = 0; s < A.nsteps; s++) {
-        const StepHdr h = nh;
-        const uint4 d0 = nd0, d1 = nd1;
-        if (s + 1 < A.nsteps) {  // next step's header and descriptor travel while this step computes
-            nh = A.hdrs[s + 1];
-            const uint4* np = dptr + (size_t)(s + 1) * K * 2;
-            nd0 = np[0]; nd1 = np[1];
+    // One 16-byte load per lane fetches the descriptors of a block of SPB steps; two blocks are
+    // kept ahead of the one being executed, so no step waits on descriptor memory.
+    constexpr int SPB = 64 / K;
+    const uint4* bptr = A.blocks + lane;
+    // (loads past the last block are clamped to it rather than skipped: a conditional load would
+    // become a flat load, which LDS waits cannot tell apart from LDS traffic)
+    const int last_block = A.nblocks - 1;
+    uint4 cur = bptr[0];
+    uint4 nxt = bptr[(size_t)min(1, last_block) * 64];
+    long long t_prev = 0;
+    int k_prev = -1;
+    int s = 0;
+    for (int b = 0; b < A.nblocks; b++) {
+      const uint4 ahead = bptr[(size_t)min(b + 2, last_block) * 64];
+      for (int j = 0; j < SPB && s < A.nsteps; j++, s++) {
+        // this lane's descriptor lives in lane j * K + role
+        const int from = (j * K + role) * 4;
+        const u32 dx = (u32)__builtin_amdgcn_ds_bpermute(from, (int)cur.x);
+        const u32 dy = (u32)__builtin_amdgcn_ds_bpermute(from, (int)cur.y);
+        const u32 dz = (u32)__builtin_amdgcn_ds_bpermute(from, (int)cur.z);
+        const u32 hx = (u32)__builtin_amdgcn_readfirstlane((int)dx);  // step-wide fields
+        const u32 type = (hx >> 3) & 3u, max_terms = (hx >> 5) & 7u, flags = (hx >> 8) & 3u;
+        if (TAG == TAG_PROFILE && tid == 0 && blockIdx.x == 0) {
+            const long long now = clock64();
+            if (k_prev >= 0) {
+                atomicAdd(A.prof + k_prev, (unsigned long long)(now - t_prev));
+                atomicAdd(A.prof + 16 + k_prev, 1ull);
+            }
+            t_prev = now;
+            k_prev = type == ST_COPY ? 4 + (int)((hx >> 10) & 7u) : (type == ST_LIN ? (flags & 2u ? 9 : (flags ? 2 : 1)) : (int)type);
         }
-        const bool on = lane_on && (d0.x & 1u);
-        // descriptor words: w[i] lives in dword 1 + i/2 of the 8-dword descriptor
-        const u32 dw[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-        auto W = [&](int i) -> u32 { return (dw[1 + (i >> 1)] >> ((i & 1) * 16)) & 0xffffu; };
+        const bool on = lane_on && (dx & 1u);
+        const u32 dst = dx >> 16;
+        auto OP = [&](int i) -> u32 { return ((i < 4 ? dy : dz) >> ((i & 3) * 8)) & 0xffu; };
 
         // Multiplier and sum steps are branch-free: idle lanes read the ZERO slot and store to TRASH.
-        if (h.type == ST_FMUL) {
-            u32 a[12], b[12], r[12];
-            lds_load(W(1), a);
-            lds_load(W(2), b);
-            fp_mul(a, b, r);
-            lds_store(W(0), r);
-        } else if (h.type == ST_DOT2) {
-            u32 a[12], b[12], c[12], d[12], r[12];
-            lds_load(W(1), a);
-            lds_load(W(2), b);
-            lds_load(W(3), c);
-            lds_load(W(4), d);
-            if (d0.x & 4u) {  // a*b - c*d: d <- k*p - d (k*p >= d by the scheduler's bound)
-                const uint4* row = kp_lds + ((d0.x >> 16) & 0xffu) * 4;
-                uint4 r0 = row[0], r1 = row[1], r2 = row[2];
-                u32 q[12];
-                unpack3(r0, r1, r2, q);
-                carry_t cy;
-                d[0] = sub_co(q[0], d[0], cy);
-#pragma unroll
-                for (int i = 1; i < 12; i++) d[i] = subb_co(q[i], d[i], cy);
-            }
-            fp_dot2(a, b, c, d, r);
-            lds_store(W(0), r);
-        } else if (h.type == ST_LIN) {
-            // acc = bias + sum(+/- terms) in 13-limb two's complement; bias = k*p makes it >= 0
-            u32 acc[13];
-            const u32 kb = (d0.x >> 16) & 0xffu;
+        if (type == ST_FMUL) {
+            u32 a[D28], b[D28], r[D28];
+            lds_load(OP(0), a);
+            lds_load(OP(1), b);
+            fp28_mul(a, b, r);
+            lds_store(dst, r);
+        } else if (type == ST_DOT2) {
+            u32 a[D28], b[D28], c[D28], d[D28], r[D28];
+            lds_load(OP(0), a);
+            lds_load(OP(1), b);
+            lds_load(OP(2), c);
+            lds_load(OP(3), d);
             {
-                const uint4* row = kp_lds + kb * 4;
-                uint4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
-                unpack3(r0, r1, r2, acc);
-                acc[12] = r3.x;
+                // a*b - c*d: negate d digit by digit, -d = (d ^ -1) + 1
+                const u32 m = (dx & 4u) ? 0xffffffffu : 0u;
+                const u32 one = m & 1u;
+#pragma unroll
+                for (int i = 0; i < D28; i++) d[i] = (d[i] ^ m) + one;
             }
+            fp28_dot2(a, b, c, d, r);
+            lds_store(dst, r);
+        } else if (type == ST_LIN) {
+            // acc = sum of (x ^ m), m = -1 for negated terms: each of those is one short of -x
+            u32 acc[D28];
+            const u32 nneg = (dx >> 13) & 7u;
+#pragma unroll
+            for (int i = 0; i < D28; i++) acc[i] = nneg;
 #pragma unroll
             for (int t = 0; t < LIN_MAX_TERMS; t++) {
-                if (t < (int)(h.max_terms & 0xffu)) {  // uniform; short sums are padded with +ZERO
-                    const u32 w = W(1 + t);
-                    const u32 m = (w & 0x8000u) ? 0xffffffffu : 0u;
-                    u32 x[12], y[12];
-                    lds_load(w & 0x7fffu, x);
-#pragma unroll
-                    for (int i = 0; i < 12; i++) y[i] = x[i] ^ m;
-                    lin_accumulate(acc, y, m);  // acc += x, or acc += ~x + 1
+                if (t < (int)max_terms) {  // uniform; short sums are padded with +ZERO
+                    const u32 w = OP(t);
+                    const u32 m = (w & 0x80u) ? 0xffffffffu : 0u;
+                    u32 x[D28];
+                    lds_load(w & 0x7fu, x);
+                    xor_add28(acc, x, m);
                 }
             }
-            // conditional subtraction of 2^j * p, j = rounds-1 .. 0
-            const u32 rounds = (h.max_terms >> 8) & 0xffu;
-            if (rounds > 4) cond_sub_kp<4>(acc);  // 16p
-            if (rounds > 3) cond_sub_kp<3>(acc);
-            if (rounds > 2) cond_sub_kp<2>(acc);
-            if (rounds > 1) cond_sub_kp<1>(acc);
-            if (rounds > 0) cond_sub_kp<0>(acc);
-            lds_store(W(0), acc);
+            if (flags & 2u) reduce28(acc);  // sweeps as well
+            else if (flags) normalise28(acc);
+            lds_store(dst, acc);
         } else {  // ST_COPY: every lane reads before any lane writes
-            const u32 kind = (d0.x >> 8) & 0xffu;
-            const u32 dst = W(0), src = W(1);
-            uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0;
+            const u32 kind = (dx >> 10) & 7u;
+            const u32 src = dy;
+            // A fill may read what an earlier spill of this wave wrote (spills themselves are not
+            // waited for): drain the wave's stores first.
+            if (__builtin_amdgcn_ballot_w64(on && kind == CK_FILL) != 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            u32 v[D28];
+#pragma unroll
+            for (int i = 0; i < D28; i++) v[i] = 0;
             if (on) {
-                if (kind == CK_IN || kind == CK_FILL) {
-                    const uint4* p = (kind == CK_IN ? A.gin : A.gtmp) + ((size_t)src * 3) * A.npad + e;
-                    v0 = p[0]; v1 = p[A.npad]; v2 = p[2 * (size_t)A.npad];
+                if (kind == CK_IN) {
+                    const uint4* p = A.gin + ((size_t)src * 3) * A.npad + e;
+                    uint4 v0 = p[0], v1 = p[A.npad], v2 = p[2 * (size_t)A.npad];
+                    u32 l[12];
+                    unpack3(v0, v1, v2, l);
+                    unpack28(l, v);
+                } else if (kind == CK_FILL) {
+                    const uint4* p = A.gtmp + ((size_t)src * 3) * A.npad + e;
+                    uint4 v0 = p[0], v1 = p[A.npad], v2 = p[2 * (size_t)A.npad];
+                    uint2 t = A.gtmp_tail[(size_t)src * A.npad + e];
+                    unpack3(v0, v1, v2, v);
+                    v[12] = t.x; v[13] = t.y;
                 } else if (kind == CK_CONST) {
-                    const uint4* p = A.consts + (size_t)src * 3;
-                    v0 = p[0]; v1 = p[1]; v2 = p[2];
+                    const uint4* p = A.consts + (size_t)src * 4;
+                    uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+                    unpack3(v0, v1, v2, v);
+                    v[12] = v3.x; v[13] = v3.y;
                 } else {
-                    const uint4* p = lds + (size_t)src * 3 * GPW + g;
-                    v0 = p[0]; v1 = p[GPW]; v2 = p[2 * GPW];
+                    lds_load(src, v);
                 }
             }
+            // Every path consumes the loaded registers here.  Otherwise the compiler must assume a
+            // load may still be in flight when other steps reuse those registers and guards them
+            // with waits that also stall on unrelated stores and descriptor prefetches.
+            asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                              "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]));
             if (on) {
                 if (kind <= CK_CONST) {
-                    uint4* p = lds + (size_t)dst * 3 * GPW + g;
-                    p[0] = v0; p[GPW] = v1; p[2 * GPW] = v2;
-                } else {
-                    uint4* p = (kind == CK_SPILL ? A.gtmp : A.gout) + ((size_t)dst * 3) * A.npad + e;
-                    p[0] = v0; p[A.npad] = v1; p[2 * (size_t)A.npad] = v2;
+                    lds_store(dst, v);
+                } else if (kind == CK_SPILL) {
+                    uint4* p = A.gtmp + ((size_t)dst * 3) * A.npad + e;
+                    p[0] = make_uint4(v[0], v[1], v[2], v[3]);
+                    p[A.npad] = make_uint4(v[4], v[5], v[6], v[7]);
+                    p[2 * (size_t)A.npad] = make_uint4(v[8], v[9], v[10], v[11]);
+                    A.gtmp_tail[(size_t)dst * A.npad + e] = make_uint2(v[12], v[13]);
+                } else {  // CK_OUT: below 2p -> canonical, 12 x u32
+                    canon28(v);
+                    u32 l[12];
+                    pack28(v, l);
+                    uint4* p = A.gout + ((size_t)dst * 3) * A.npad + e;
+                    p[0] = make_uint4(l[0], l[1], l[2], l[3]);
+                    p[A.npad] = make_uint4(l[4], l[5], l[6], l[7]);
+                    p[2 * (size_t)A.npad] = make_uint4(l[8], l[9], l[10], l[11]);
                 }
             }
-            // spilled values may be filled by another lane of this wave in a later step
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         }
+      }
+      cur = nxt;
+      nxt = ahead;
+    }
+    if (TAG == TAG_PROFILE && tid == 0 && blockIdx.x == 0 && k_prev >= 0) {
+        atomicAdd(A.prof + k_prev, (unsigned long long)(clock64() - t_prev));
+        atomicAdd(A.prof + 16 + k_prev, 1ull);
     }
 }
 

@@ -43,12 +43,26 @@ def test_no_cpu_fallback():
 
 
 def test_constant_table():
+    """The interpreter's constants carry the Montgomery factor 2^392 (14 digits of 28 bits)."""
     c = S.get_constants()
-    assert F(c[0]) == 1 and F(c[1]) == R.TWO_INV and c[18] == 1 and c[17] == M(R.MONT_R)
+    F28 = lambda x: x * pow(1 << 392, -1, R.P) % R.P
+    assert F28(c[0]) == 1 and F28(c[1]) == R.TWO_INV
+    assert c[17] == pow(2, 400, R.P) and c[18] == pow(2, 384, R.P) and c[19] == pow(2, 784, R.P) and c[20] == 1
     g1, g2 = R.frob_coeffs(1), R.frob_coeffs(2)
     for i in range(1, 6):
-        assert (F(c[2 + 2 * (i - 1)]), F(c[3 + 2 * (i - 1)])) == R.fq2_pow(g1, i)
-        assert F(c[12 + i - 1]) == R.fq2_pow(g2, i)[0]
+        assert (F28(c[2 + 2 * (i - 1)]), F28(c[3 + 2 * (i - 1)])) == R.fq2_pow(g1, i)
+        assert F28(c[12 + i - 1]) == R.fq2_pow(g2, i)[0]
+
+
+def test_simulator_multiplier_forms_agree():
+    """The whole-number form of the Montgomery product sum equals the column-wise form the kernel runs,
+    signed and unnormalised digits included."""
+    import random
+    rng = random.Random(5)
+    for _ in range(200):
+        ops = [[rng.randrange(-(1 << 29), 1 << 29) for _ in range(13)] + [rng.randrange(-(1 << 22), 1 << 22)] for _ in range(4)]
+        assert S.mulacc(*ops) == S.mulacc_columns(*ops)
+        assert S.mulacc(ops[0], ops[1]) == S.mulacc_columns(ops[0], ops[1])
 
 
 @pytest.mark.parametrize("K,slots", [(8, 0), (6, 40), (9, 0), (12, 0), (16, 0)])

@@ -13,9 +13,12 @@ import bls381_ref as R
 from plonky2_bls12_381_pairing_amd import _lib
 
 P = R.P
-RINV = pow(1 << 384, -1, P)
+RBITS = 392                       # the interpreter's Montgomery factor: 14 digits of 28 bits
+PINV = pow(P, -1, 1 << RBITS)
+MUL_LIMIT = (1 << RBITS) // P     # 2520: operand-bound products a multiplication tolerates
 ST_FMUL, ST_LIN, ST_COPY, ST_DOT2 = 0, 1, 2, 3
 CK_IN, CK_FILL, CK_CONST, CK_SPILL, CK_OUT = range(5)
+N_CONST = 21
 
 
 def get_program(which, K=8, lds_slots=0):
@@ -30,18 +33,118 @@ def get_program(which, K=8, lds_slots=0):
 
 
 def get_constants():
-    n = 19
-    buf = (C.c_uint32 * (12 * n))()
-    _lib.check(_lib.lib.bls381_debug_constants(buf, n))
-    return [R.u32_limbs_to_int(buf[12 * i:12 * i + 12]) for i in range(n)]
+    buf = (C.c_uint32 * (16 * N_CONST))()
+    _lib.check(_lib.lib.bls381_debug_constants(buf, N_CONST))
+    out = []
+    for i in range(N_CONST):
+        row = buf[16 * i:16 * i + 16]
+        assert all(d < 1 << 28 for d in row[:14]) and row[14] == 0 and row[15] == 0
+        out.append(sum(d << (28 * k) for k, d in enumerate(row[:14])))
+    return out
+
+
+MASK = (1 << 28) - 1
+P28 = [(P >> (28 * i)) & MASK for i in range(14)]
+N28 = (-pow(P, -1, 1 << 28)) % (1 << 28)
+
+
+def to_digits(v):
+    assert 0 <= v < 1 << RBITS
+    return [(v >> (28 * i)) & MASK for i in range(14)]
+
+
+def value(d):
+    return sum(x << (28 * i) for i, x in enumerate(d))
+
+
+def s32(x):
+    """What a 32-bit register holding x means as a signed number; the kernel's digits are those."""
+    assert -(1 << 31) <= x < (1 << 31), "digit leaves 32 bits"
+    return x
+
+
+def mulacc(a, b, c=None, d=None):
+    """The kernel's column-wise Montgomery product sum.  The result is determined by its value (digits
+    0..12 normalised, signed top digit), so it is computed on whole numbers; the 64-bit column
+    accumulator is checked through the worst column: 14 products per operand pair, 14 reduction
+    products and the carry."""
+    worst = 14 * max(abs(x) for x in a) * max(abs(x) for x in b) + 14 * MASK * MASK + (1 << 36)
+    t = value(a) * value(b)
+    if c is not None:
+        worst += 14 * max(abs(x) for x in c) * max(abs(x) for x in d)
+        t += value(c) * value(d)
+    assert worst < 1 << 63, "column accumulator leaves 64 bits"
+    m = (-t * PINV) % (1 << RBITS)
+    r = (t + m * P) >> RBITS
+    return [(r >> (28 * i)) & MASK for i in range(13)] + [s32(r >> (28 * 13))]
+
+
+def mulacc_columns(a, b, c=None, d=None):
+    """Digit-for-digit form of mulacc (what the kernel executes); the tests cross-check the two."""
+    m = [0] * 14
+    r = [0] * 14
+    acc = 0
+
+    def chk():
+        assert -(1 << 63) <= acc < (1 << 63), "column accumulator leaves 64 bits"
+    for k in range(14):
+        for i in range(k + 1):
+            acc += a[i] * b[k - i]
+            if c is not None:
+                acc += c[i] * d[k - i]
+        for j in range(k):
+            acc += m[j] * P28[k - j]
+        m[k] = ((acc & 0xffffffff) * N28) & MASK
+        acc += m[k] * P28[0]
+        chk()
+        assert acc & MASK == 0
+        acc >>= 28
+    for k in range(14, 27):
+        for i in range(k - 13, 14):
+            acc += a[i] * b[k - i]
+            if c is not None:
+                acc += c[i] * d[k - i]
+            acc += m[i] * P28[k - i]
+        chk()
+        r[k - 14] = acc & MASK
+        acc >>= 28
+    r[13] = s32(acc)
+    return r
+
+
+def normalise(d):
+    d = list(d)
+    for i in range(13):
+        carry = d[i] >> 28
+        d[i] &= MASK
+        d[i + 1] = s32(d[i + 1] + carry)
+    return d
+
+
+def reduce(d):
+    d = list(d)
+    q = (d[13] * 40323) >> 32
+    c = 0
+    for i in range(14):
+        c += q * P28[i]
+        d[i] = s32(d[i] - (c & MASK if i < 13 else c))   # the top digit takes what is left, sign included
+        c >>= 28
+    return normalise(d)
+
+
+def canon(d):
+    v = value(d)
+    assert all(0 <= x <= MASK for x in d[:13]), "stored value is not normalised"
+    assert -P < v < 2 * P, "stored value outside (-p, 2p)"
+    return v + P if v < 0 else (v - P if v >= P else v)
 
 
 def run_program(prog, gin, strict=True):
-    """gin: list of ints (Montgomery residues, one per input slot).  Returns gout list."""
+    """gin: list of ints in boundary form (12 x u32 patterns), one per input slot.  Returns gout list."""
     K = prog["K"]
-    consts = get_constants()
+    consts = [to_digits(c) for c in get_constants()]
     lds = [None] * prog["lds_slots"]
-    lds[prog["lds_slots"] - 2] = 0            # the ZERO slot; the last slot is TRASH
+    lds[prog["lds_slots"] - 2] = [0] * 14      # the ZERO slot; the last slot is TRASH
     gtmp = {}
     gout = [None] * prog["n_out"]
     hd, ds = prog["hdrs"], prog["descs"]
@@ -61,43 +164,50 @@ def run_program(prog, gin, strict=True):
             if typ == ST_FMUL:
                 a, b = lds[w[1]], lds[w[2]]
                 assert a is not None and b is not None, "FMUL reads an empty slot"
-                assert a * b < P << 384, "FMUL operands exceed the Montgomery bound"
-                writes.append(("lds", w[0], a * b * RINV % P))
+                assert abs(value(a) * value(b)) < MUL_LIMIT * P * P, "FMUL operands exceed the Montgomery bound"
+                out = mulacc(a, b)
+                assert (value(out) << RBITS) % P == value(a) * value(b) % P and -P < value(out) < 2 * P
+                writes.append(("lds", w[0], out))
             elif typ == ST_DOT2:
                 a, b = lds[w[1]], lds[w[2]]
                 c2, d2 = lds[w[3]], lds[w[4]]
                 assert None not in (a, b, c2, d2), "DOT2 reads an empty slot"
                 if not d[0] & 2:
-                    assert c2 == 0 and d2 == 0          # single product: padded with ZERO
+                    assert value(c2) == 0 and value(d2) == 0          # single product: padded with ZERO
                 if d[0] & 4:
-                    kd = (d[0] >> 16) & 0xff
-                    assert d2 <= kd * P, "negated operand exceeds its bound"
-                    d2 = kd * P - d2
-                assert a * b + c2 * d2 < P << 384, "DOT2 operands exceed the Montgomery bound"
-                writes.append(("lds", w[0], (a * b + c2 * d2) * RINV % P))
+                    d2 = [s32(-x) for x in d2]
+                t = value(a) * value(b) + value(c2) * value(d2)
+                assert abs(value(a) * value(b)) + abs(value(c2) * value(d2)) < MUL_LIMIT * P * P, "DOT2 operands exceed the Montgomery bound"
+                out = mulacc(a, b, c2, d2)
+                assert (value(out) << RBITS) % P == t % P and -P < value(out) < 2 * P
+                writes.append(("lds", w[0], out))
             elif typ == ST_LIN:
                 nt = (d[0] >> 8) & 0xff
-                kb = (d[0] >> 16) & 0xff
-                assert nt <= (mt & 0xff) and kb <= 16
-                acc = kb * P
+                nneg = d[0] >> 24
+                assert nt <= (mt & 0xff) <= 7
+                acc = [0] * 14
+                negs = 0
                 for t in range(mt & 0xff):
                     v = lds[w[1 + t] & 0x7fff]
-                    if t >= nt:
-                        assert v == 0 and not w[1 + t] & 0x8000
                     assert v is not None, "LIN reads an empty slot"
-                    acc += -v if w[1 + t] & 0x8000 else v
-                assert 0 <= acc < 1 << 416, "13-limb accumulator out of range"
-                rounds = (mt >> 8) & 0xff
-                assert rounds <= 5
-                for j in range(rounds - 1, -1, -1):         # the kernel's ladder 2^(r-1) p ... p
-                    if acc >= (P << j):
-                        acc -= P << j
-                assert acc < 1 << 384, "unreduced value does not fit 12 limbs"
+                    if t >= nt:
+                        assert value(v) == 0 and not w[1 + t] & 0x8000
+                    sign = -1 if w[1 + t] & 0x8000 else 1
+                    negs += sign < 0
+                    acc = [s32(x + sign * y) for x, y in zip(acc, v)]
+                assert negs == nneg, "negated-term count in the descriptor is wrong"
+                assert abs(value(acc)) < MUL_LIMIT * P
+                if mt & 0x200:
+                    acc = reduce(acc)                # sweeps as well
+                    assert -P < value(acc) < 2 * P
+                elif mt & 0x100:
+                    acc = normalise(acc)
                 writes.append(("lds", w[0], acc))
             else:
                 kind = (d[0] >> 8) & 0xff
                 if kind == CK_IN:
-                    writes.append(("lds", w[0], gin[w[1]]))
+                    assert gin[w[1]] < 1 << 384
+                    writes.append(("lds", w[0], to_digits(gin[w[1]])))
                 elif kind == CK_FILL:
                     writes.append(("lds", w[0], gtmp[w[1]]))
                 elif kind == CK_CONST:
@@ -106,8 +216,8 @@ def run_program(prog, gin, strict=True):
                     assert lds[w[1]] is not None
                     writes.append(("tmp", w[0], lds[w[1]]))
                 else:
-                    assert lds[w[1]] is not None and lds[w[1]] < P, "stored value is not canonical"
-                    writes.append(("out", w[0], lds[w[1]]))
+                    assert lds[w[1]] is not None
+                    writes.append(("out", w[0], canon(lds[w[1]])))
         seen = set()
         for where, idx, v in writes:
             assert (where, idx) not in seen, "two lanes write one slot in one step"
