@@ -761,6 +761,7 @@ extern "C" int bls381_debug_program(const char* which, int K, int lds_slots, uin
         fprintf(stderr, "%s K=%d slots=%d: steps %zu (mul %d, dot2 %d, sum %d, copy %d) ops: mul %d dot2 %d sum %d (terms %d, reducing %d, sweeping %d) copy %d tmp %d\n",
                 which, K, lds_slots, p.hdrs.size(), p.n_fmul_steps, p.n_dot2_steps, p.n_lin_steps, p.n_copy_steps, p.n_fmul,
                 p.n_dot2, p.n_lin, p.n_lin_terms, p.n_reduce, p.n_norm, p.n_copy, p.n_tmp_slots);
+    if (getenv("BLS381_SCHED_STATS")) fprintf(stderr, "   carried fills %d, carried spills %d\n", p.n_piggy_fill, p.n_piggy_spill);
     if (hdrs && descs) {
         if (capacity_steps < p.hdrs.size()) return fail(BLS381_ERR_INVALID, "capacity too small");
         std::memcpy(hdrs, p.hdrs.data(), p.hdrs.size() * sizeof(StepHdr));

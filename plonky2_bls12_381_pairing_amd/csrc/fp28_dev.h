@@ -123,6 +123,28 @@ __device__ __forceinline__ void xor_add28(u32* acc, const u32* x, u32 m) {
           "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]), "v"(x[13]), "v"(m));
 }
 
+// acc[i] = (x[i] ^ m) + c: the first term of a sum, c = the sum's count of negated terms.
+__device__ __forceinline__ void xor_add28_first(u32* acc, const u32* x, u32 m, u32 c) {
+    asm("v_xad_u32 %0, %14, %28, %29\n\t"
+        "v_xad_u32 %1, %15, %28, %29\n\t"
+        "v_xad_u32 %2, %16, %28, %29\n\t"
+        "v_xad_u32 %3, %17, %28, %29\n\t"
+        "v_xad_u32 %4, %18, %28, %29\n\t"
+        "v_xad_u32 %5, %19, %28, %29\n\t"
+        "v_xad_u32 %6, %20, %28, %29\n\t"
+        "v_xad_u32 %7, %21, %28, %29\n\t"
+        "v_xad_u32 %8, %22, %28, %29\n\t"
+        "v_xad_u32 %9, %23, %28, %29\n\t"
+        "v_xad_u32 %10, %24, %28, %29\n\t"
+        "v_xad_u32 %11, %25, %28, %29\n\t"
+        "v_xad_u32 %12, %26, %28, %29\n\t"
+        "v_xad_u32 %13, %27, %28, %29"
+        : "=&v"(acc[0]), "=&v"(acc[1]), "=&v"(acc[2]), "=&v"(acc[3]), "=&v"(acc[4]), "=&v"(acc[5]), "=&v"(acc[6]),
+          "=&v"(acc[7]), "=&v"(acc[8]), "=&v"(acc[9]), "=&v"(acc[10]), "=&v"(acc[11]), "=&v"(acc[12]), "=&v"(acc[13])
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]),
+          "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]), "v"(x[13]), "v"(m), "v"(c));
+}
+
 // Digits of magnitude up to 7 * 2^28, |value| below 2500 p  ->  normalised, value in (-0.2 p, 1.2 p):
 // subtracts q * p, q = an estimate of value / p from the top digit (the carries still owed to it
 // move it by at most 8, 1e-4 of p's top digit), then sweeps.

@@ -334,33 +334,71 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         ops.clear();
     };
 
+    // Copies ride on compute steps where they can ("piggyback"): a lane of a multiplier or sum step
+    // may, besides its operation, spill one LDS slot (read and stored as the step starts) and fill one
+    // (global loads issued as the step starts, LDS written after the step's results).  So a fill for
+    // step s rides on the compute step before it, with its latency behind that step's arithmetic, and
+    // an eviction rides on the step whose start still sees the victim.  What cannot ride (no carrier,
+    // carrier full, victim produced by the carrier itself) becomes a copy step as before.
+    bool prev_open = false;      // the last emitted step is a compute step nothing has followed yet
+    size_t prev_idx = 0;         // its index in P.hdrs
+    std::set<int> prev_results;  // nodes it produces
+    int prev_nfill = 0, prev_nspill = 0;
+    std::set<int> prev_spilled;  // spill-array slots written by spills riding on it
+    const bool piggyback = getenv("BLS381_NO_PIGGYBACK") == nullptr;
+
     for (int s = 0; s < S; s++) {
         const RawStep& st = raw[s];
         std::set<int> srcs;
         for (int op : st.ops) for_each_src(N[op], [&](int x) { srcs.insert(x); });
         std::vector<CopyOp> spills_a, spills_b, fills;
-        std::vector<CopyOp>* spills = &spills_a;
+        std::vector<std::pair<int, int>> cur_spills;  // (LDS slot, spill-array slot) riding on this step
         std::set<int> pinned(srcs.begin(), srcs.end());  // may not be evicted while forming this step
+        const bool carrier_prev = piggyback && prev_open;
+        const bool carrier_cur = piggyback && st.cls != OC_COPY;
 
-        auto take_slot = [&]() -> int {
+        // how the slot's previous occupant left: 0 nothing to do, 1 spill rides, 2 spill is a copy step
+        auto take_slot = [&](bool for_fill, int& how) -> int {
+            how = 0;
             if (!free_lds.empty()) { int x = free_lds.back(); free_lds.pop_back(); return x; }
-            // evict the resident value with the furthest next use
+            // evict the resident value with the furthest next use; for a fill prefer victims the
+            // carrier does not produce (their spill can ride on it)
             int victim = -1, far = -1;
-            for (int sl = 0; sl < lds_slots; sl++) {
-                int o = owner[sl];
-                if (o < 0 || pinned.count(o)) continue;
-                int nu = next_use(o, s - 1);
-                if (nu > far) { far = nu; victim = sl; }
-            }
+            for (int pass = 0; pass < 2 && victim < 0; pass++)
+                for (int sl = 0; sl < lds_slots; sl++) {
+                    int o = owner[sl];
+                    if (o < 0 || pinned.count(o)) continue;
+                    if (pass == 0 && for_fill && carrier_prev && prev_results.count(o)) continue;
+                    int nu = next_use(o, s - 1);
+                    if (nu > far) { far = nu; victim = sl; }
+                }
             if (victim < 0) throw std::runtime_error("scheduler: LDS slots exhausted (" + name + ")");
             int o = owner[victim];
             bool clean = (N[o].kind == NK_LOADIN || N[o].kind == NK_LOADC || tmp_of[o] >= 0);
+            const bool from_prev = carrier_prev && prev_results.count(o);
             if (!clean && far != 0x7fffffff) {
                 int t;
                 if (!free_tmp.empty()) { t = free_tmp.back(); free_tmp.pop_back(); }
                 else t = n_tmp++;
                 tmp_of[o] = t;
-                spills->push_back(CopyOp{CK_SPILL, t, victim});
+                if (for_fill) {
+                    if (carrier_prev && !from_prev && prev_nspill < K) {
+                        OpDesc& d = P.descs[prev_idx * K + prev_nspill++];
+                        d.w[11] = (uint16_t)(victim | 0x8000); d.w[12] = (uint16_t)t;
+                        prev_spilled.insert(t);
+                        P.hdrs[prev_idx].max_terms |= 1u << 17;
+                        P.n_piggy_spill++;
+                        how = 1;
+                    } else {
+                        spills_a.push_back(CopyOp{CK_SPILL, t, victim});
+                        how = 2;
+                    }
+                } else {
+                    if (carrier_cur && (int)cur_spills.size() < K) { cur_spills.push_back({victim, t}); how = 1; }
+                    else { spills_b.push_back(CopyOp{CK_SPILL, t, victim}); how = 2; }
+                }
+            } else if (from_prev) {
+                how = 2;  // the carrier writes this slot itself: nothing may be filled into it while it runs
             }
             lds_of[o] = -1; owner[victim] = -1;
             return victim;
@@ -369,11 +407,23 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         // 1. bring non-resident sources back
         for (int x : srcs) {
             if (lds_of[x] >= 0) continue;
-            int sl = take_slot();
+            int how;
+            int sl = take_slot(true, how);
             lds_of[x] = sl; owner[sl] = x;
-            if (N[x].kind == NK_LOADIN) fills.push_back(CopyOp{CK_IN, sl, N[x].idx});
-            else if (N[x].kind == NK_LOADC) fills.push_back(CopyOp{CK_CONST, sl, N[x].idx});
-            else { assert(tmp_of[x] >= 0); fills.push_back(CopyOp{CK_FILL, sl, tmp_of[x]}); }
+            CopyOp f;
+            if (N[x].kind == NK_LOADIN) f = CopyOp{CK_IN, sl, N[x].idx};
+            else if (N[x].kind == NK_LOADC) f = CopyOp{CK_CONST, sl, N[x].idx};
+            else { assert(tmp_of[x] >= 0); f = CopyOp{CK_FILL, sl, tmp_of[x]}; }
+            // (a step's fills are loaded before its spills are stored: it must not fill what it spills)
+            const bool aliases = f.kind == CK_FILL && prev_spilled.count(f.src);
+            if (carrier_prev && how != 2 && prev_nfill < K && f.src < 128 && !aliases) {
+                OpDesc& d = P.descs[prev_idx * K + prev_nfill++];
+                d.w[9] = (uint16_t)(sl | 0x8000); d.w[10] = (uint16_t)(f.src | ((uint32_t)f.kind << 12));
+                P.hdrs[prev_idx].max_terms |= 1u << 16;
+                P.n_piggy_fill++;
+            } else {
+                fills.push_back(f);
+            }
         }
         // record operand slots now (before any source slot is recycled for a destination)
         std::map<int, int> src_slot;
@@ -387,12 +437,13 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
             }
         }
         // 3. destinations.  Spills made from here on may reuse a spill-array slot released in (2),
-        //    which a fill of this very step still has to read: they run after the fills.
-        spills = &spills_b;
+        //    which a fill of this very step still has to read: they run after the fills (those that
+        //    ride on this step do: every fill for it has landed before it starts).
         std::map<int, int> dst_slot;
         for (int op : st.ops) {
             if (N[op].kind == NK_STOREOUT) continue;
-            int sl = take_slot();
+            int how;
+            int sl = take_slot(false, how);
             lds_of[op] = sl; owner[sl] = op; dst_slot[op] = sl;
             pinned.insert(op);
         }
@@ -412,7 +463,11 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
             OpDesc d; std::memset(&d, 0, sizeof d);
             if (st.cls != OC_COPY) {  // idle lane / padding defaults
                 d.w[0] = (uint16_t)TRASH_SLOT;
-                for (int t = 1; t < 14; t++) d.w[t] = (uint16_t)ZERO_SLOT;
+                for (int t = 1; t <= 8; t++) d.w[t] = (uint16_t)ZERO_SLOT;
+                if (r < (int)cur_spills.size()) {
+                    d.w[11] = (uint16_t)(cur_spills[r].first | 0x8000); d.w[12] = (uint16_t)cur_spills[r].second;
+                    P.n_piggy_spill++;
+                }
             }
             if (r < (int)st.ops.size()) {
                 int op = st.ops[r];
@@ -459,7 +514,15 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
             P.descs.push_back(d);
         }
         if (st.cls == OC_LIN) h.max_terms |= (uint32_t)step_rounds << 8;  // carry sweep / reduction wanted by some op
+        if (!cur_spills.empty()) h.max_terms |= 1u << 17;
         P.hdrs.push_back(h);
+        prev_open = st.cls != OC_COPY;
+        prev_idx = P.hdrs.size() - 1;
+        prev_results.clear();
+        for (int op : st.ops) if (N[op].kind != NK_STOREOUT) prev_results.insert(op);
+        prev_nfill = 0; prev_nspill = (int)cur_spills.size();
+        prev_spilled.clear();
+        for (auto& cs : cur_spills) prev_spilled.insert(cs.second);
         if (st.cls == OC_FMUL && any_dot2) P.n_dot2_steps++;
         else if (st.cls == OC_FMUL) P.n_fmul_steps++;
         else if (st.cls == OC_LIN) P.n_lin_steps++;

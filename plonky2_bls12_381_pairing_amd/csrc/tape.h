@@ -56,6 +56,7 @@ struct Program {
     // statistics
     int n_fmul = 0, n_lin = 0, n_lin_terms = 0, n_copy = 0, n_dot2 = 0;
     int n_fmul_steps = 0, n_lin_steps = 0, n_copy_steps = 0, n_dot2_steps = 0;
+    int n_piggy_fill = 0, n_piggy_spill = 0;  // copies riding on compute steps
     int n_reduce = 0, n_norm = 0;  // sums followed by a reduction / by a carry sweep only
 };
 

@@ -80,10 +80,11 @@ SFq2 Tower::mul(const SFq2& a, const SFq2& b) {
 SFq2 Tower::sqr(const SFq2& a) {
     if (a.c1.is_zero()) return {mul(a.c0, a.c0), SZERO};
     if (a.c0.is_zero()) return {neg(mul(a.c1, a.c1)), SZERO};
-    SFp s = add(a.c0, a.c1), df = sub(a.c0, a.c1);
-    SFp c0 = mul(s, df);
-    SFp t = mul(mat(a.c0), a.c1);
-    return {c0, add(t, t)};
+    // two-product forms, no sums around them: c0 = a0 a0 - a1 a1, c1 = a0 a1 + a0 a1
+    SFp a0 = mat(a.c0), a1 = mat(a.c1);
+    SFp c0{d_.dot2(a0.id, a0.id, a1.id, a1.id, /*neg_d=*/true)};
+    SFp c1{d_.dot2(a0.id, a1.id, a0.id, a1.id)};
+    return {c0, c1};
 }
 
 // ------------------------------------------------------------------ Fq6

@@ -32,8 +32,9 @@ struct StepHdr {
     uint32_t type;       // StepType
     uint32_t max_terms;  // ST_LIN: bits 0..7 largest term count among the step's ops,
                          //         bit 8: results get a carry sweep (digits back below 2^28)
-                         //         bit 9: results are also brought into (-0.1p, 1.1p): quotient
+                         //         bit 9: results are also brought into (-0.2p, 1.2p): quotient
                          //                estimate from the top digit
+                         // multiplier and sum steps: bit 16 some lane carries a fill, bit 17 a spill
 };
 
 // One operation descriptor per (step, lane-in-group).  32 bytes.
@@ -49,6 +50,12 @@ struct StepHdr {
 //   ST_DOT2        : w[1] = a, w[2] = b, w[3] = c, w[4] = d
 //   ST_LIN         : w[1+i] = slot | (negate << 15), i < term count <= 7
 //   ST_COPY        : w[1] = source slot (LDS slot, global slot or constant id)
+//   Multiplier and sum steps may carry copies besides their operation:
+//   w[9], w[10]    : fill: w[9] = LDS slot | 0x8000 (valid), w[10] = source slot | CopyKind << 12
+//                    (CK_IN, CK_FILL or CK_CONST); the loads are issued as the step starts, the LDS
+//                    slot is written after the step's results
+//   w[11], w[12]   : spill: w[11] = LDS slot | 0x8000 (valid), w[12] = spill-array slot; read and
+//                    stored as the step starts, before the step's fills are issued
 struct OpDesc {
     uint32_t hdr;
     uint16_t w[14];
@@ -65,8 +72,12 @@ enum { LIN_MAX_TERMS = 7, MAX_LDS_SLOTS = 128 };
 //   w[0] bit 0 active, bit 1 second product, bit 2 subtract it, bits 3..4 StepType,
 //        bits 5..7 largest term count of the step, bits 8..9 sweep / reduce flags of the step,
 //        bits 10..12 CopyKind, bits 13..15 negated-term count, bits 16..31 destination slot
+//        (multiplier and sum steps: destination in bits 16..22, bit 23 some lane of the step
+//        carries a fill, bit 24 some lane carries a spill)
 //   w[1], w[2]  multiplier and sum steps: operand i in byte i, LDS slot in bits 0..6, negate in bit 7;
 //               copy steps: w[1] = source slot
+//   w[3]        carried copies: bits 0..6 fill LDS slot, 7..8 CopyKind, 9..15 source slot, 16 valid;
+//               bits 17..23 spill LDS slot, 24..30 spill-array slot, 31 valid
 struct PackedDesc {
     uint32_t w[4];
 };
@@ -79,10 +90,14 @@ inline PackedDesc pack_desc(const StepHdr& h, const OpDesc& d) {
         p.w[1] = d.w[1];
     } else {
         p.w[0] |= ((d.hdr >> 24) & 7u) << 13;
+        p.w[0] |= ((h.max_terms >> 16) & 3u) << 23;
         for (int i = 0; i < 8; i++) {
             const uint32_t b = (d.w[1 + i] & 0x7fu) | ((d.w[1 + i] & 0x8000u) ? 0x80u : 0u);
             p.w[1 + i / 4] |= b << (8 * (i % 4));
         }
+        if (d.w[9] & 0x8000u)
+            p.w[3] |= (d.w[9] & 0x7fu) | (((d.w[10] >> 12) & 3u) << 7) | ((d.w[10] & 0x7fu) << 9) | (1u << 16);
+        if (d.w[11] & 0x8000u) p.w[3] |= ((d.w[11] & 0x7fu) << 17) | ((d.w[12] & 0x7fu) << 24) | (1u << 31);
     }
     return p;
 }  // seven 2^28-bounded digits and their carries fit 32 bits

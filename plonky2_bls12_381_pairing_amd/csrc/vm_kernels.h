@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "fp_dev.h"
 #include "fp_asm_gen.h"
 #include "fp28_dev.h"
@@ -97,14 +99,26 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
     long long t_prev = 0;
     int k_prev = -1;
     int s = 0;
+    // this lane's descriptor of step j of a block lives in lane j * K + role; the one for the next
+    // step is fetched while the current step executes
+    u32 nx = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)cur.x);
+    u32 ny = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)cur.y);
+    u32 nz = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)cur.z);
     for (int b = 0; b < A.nblocks; b++) {
       const uint4 ahead = bptr[(size_t)min(b + 2, last_block) * 64];
       for (int j = 0; j < SPB && s < A.nsteps; j++, s++) {
-        // this lane's descriptor lives in lane j * K + role
-        const int from = (j * K + role) * 4;
-        const u32 dx = (u32)__builtin_amdgcn_ds_bpermute(from, (int)cur.x);
-        const u32 dy = (u32)__builtin_amdgcn_ds_bpermute(from, (int)cur.y);
-        const u32 dz = (u32)__builtin_amdgcn_ds_bpermute(from, (int)cur.z);
+        const u32 dx = nx, dy = ny, dz = nz;
+        if (j + 1 < SPB) {  // a branch, not a select: the next block's registers are touched once per block only
+            const int from = ((j + 1) * K + role) * 4;
+            nx = (u32)__builtin_amdgcn_ds_bpermute(from, (int)cur.x);
+            ny = (u32)__builtin_amdgcn_ds_bpermute(from, (int)cur.y);
+            nz = (u32)__builtin_amdgcn_ds_bpermute(from, (int)cur.z);
+        } else {
+            asm volatile("" ::: "memory");
+            nx = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)nxt.x);
+            ny = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)nxt.y);
+            nz = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)nxt.z);
+        }
         const u32 hx = (u32)__builtin_amdgcn_readfirstlane((int)dx);  // step-wide fields
         const u32 type = (hx >> 3) & 3u, max_terms = (hx >> 5) & 7u, flags = (hx >> 8) & 3u;
         if (TAG == TAG_PROFILE && tid == 0 && blockIdx.x == 0) {
@@ -117,9 +131,57 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             k_prev = type == ST_COPY ? 4 + (int)((hx >> 10) & 7u) : (type == ST_LIN ? (flags & 2u ? 9 : (flags ? 2 : 1)) : (int)type);
         }
         const bool on = lane_on && (dx & 1u);
-        const u32 dst = dx >> 16;
+        const u32 dst = type == ST_COPY ? dx >> 16 : (dx >> 16) & 0x7fu;
         auto OP = [&](int i) -> u32 { return ((i < 4 ? dy : dz) >> ((i & 3) * 8)) & 0xffu; };
 
+        // Copies carried by a multiplier or sum step.  Fill: the loads are issued now and land in LDS
+        // after the step's results, their latency behind the step's arithmetic.  Spill: LDS slot ->
+        // spill array, now, after the fills' loads (no step fills what it spills; waiting for the
+        // loads later then never waits for these stores).
+        u32 pf[D28];  // deliberately not initialised: a merge with constants would make the compiler copy
+                      // the loaded registers, and so wait for the loads, right where they are issued
+        u32 dw = 0;   // the descriptor word of the carried copies, fetched only by steps that carry any
+        const bool carries = type != ST_COPY && (hx & (3u << 23));
+        if (carries) dw = (u32)__builtin_amdgcn_ds_bpermute((j * K + role) * 4, (int)cur.w);
+        if (carries && (hx & (1u << 23))) {
+            // a fill may read what a spill of an earlier step wrote: drain the wave's stores first
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane_on && (dw & (1u << 16))) {
+                const u32 fk = (dw >> 7) & 3u, src = (dw >> 9) & 0x7fu;
+                if (fk == CK_CONST) {
+                    const uint4* p = A.consts + (size_t)src * 4;
+                    uint4 v0 = p[0], v1 = p[1], v2 = p[2];
+                    // 8 bytes, not 16: registers a load writes but nothing reads get reused at once, and
+                    // the reuse then has to wait for the load
+                    const uint2* pt = reinterpret_cast<const uint2*>(p + 3);
+                    asm volatile("" : "+v"(pt));  // keeps the compiler from widening the load again
+                    uint2 v3 = *pt;
+                    unpack3(v0, v1, v2, pf);
+                    pf[12] = v3.x; pf[13] = v3.y;
+                } else {
+                    const uint4* p = (fk == CK_IN ? A.gin : A.gtmp) + ((size_t)src * 3) * A.npad + e;
+                    uint4 v0 = p[0], v1 = p[A.npad], v2 = p[2 * (size_t)A.npad];
+                    unpack3(v0, v1, v2, pf);
+                    if (fk == CK_FILL) {
+                        uint2 t = A.gtmp_tail[(size_t)src * A.npad + e];
+                        pf[12] = t.x; pf[13] = t.y;
+                    }
+                }
+            }
+        }
+
+        if (carries && (hx & (1u << 24))) {
+            if (lane_on && (dw >> 31)) {
+                u32 v[D28];
+                lds_load((dw >> 17) & 0x7fu, v);
+                const u32 t = (dw >> 24) & 0x7fu;
+                uint4* p = A.gtmp + ((size_t)t * 3) * A.npad + e;
+                p[0] = make_uint4(v[0], v[1], v[2], v[3]);
+                p[A.npad] = make_uint4(v[4], v[5], v[6], v[7]);
+                p[2 * (size_t)A.npad] = make_uint4(v[8], v[9], v[10], v[11]);
+                A.gtmp_tail[(size_t)t * A.npad + e] = make_uint2(v[12], v[13]);
+            }
+        }
         // Multiplier and sum steps are branch-free: idle lanes read the ZERO slot and store to TRASH.
         if (type == ST_FMUL) {
             u32 a[D28], b[D28], r[D28];
@@ -143,21 +205,37 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             fp28_dot2(a, b, c, d, r);
             lds_store(dst, r);
         } else if (type == ST_LIN) {
-            // acc = sum of (x ^ m), m = -1 for negated terms: each of those is one short of -x
+            // acc = sum of (x ^ m), m = -1 for negated terms: each of those is one short of -x, which
+            // the first term makes up for by starting from the count of negated terms.  The loads
+            // of up to four terms are issued together so their latencies overlap.
             u32 acc[D28];
             const u32 nneg = (dx >> 13) & 7u;
+            auto terms = [&](auto first_tag, auto count_tag) {
+                constexpr int T0 = decltype(first_tag)::value, N = decltype(count_tag)::value;
+                u32 x[N][D28], m[N];
 #pragma unroll
-            for (int i = 0; i < D28; i++) acc[i] = nneg;
-#pragma unroll
-            for (int t = 0; t < LIN_MAX_TERMS; t++) {
-                if (t < (int)max_terms) {  // uniform; short sums are padded with +ZERO
-                    const u32 w = OP(t);
-                    const u32 m = (w & 0x80u) ? 0xffffffffu : 0u;
-                    u32 x[D28];
-                    lds_load(w & 0x7fu, x);
-                    xor_add28(acc, x, m);
+                for (int t = 0; t < N; t++) {
+                    const u32 w = OP(T0 + t);
+                    m[t] = (w & 0x80u) ? 0xffffffffu : 0u;
+                    lds_load(w & 0x7fu, x[t]);
                 }
+#pragma unroll
+                for (int t = 0; t < N; t++) {
+                    if (T0 + t == 0) xor_add28_first(acc, x[t], m[t], nneg);
+                    else xor_add28(acc, x[t], m[t]);
+                }
+            };
+#define BLS381_IC(n) std::integral_constant<int, n>()
+            switch (max_terms) {  // uniform; short sums are padded with +ZERO
+                case 1: terms(BLS381_IC(0), BLS381_IC(1)); break;
+                case 2: terms(BLS381_IC(0), BLS381_IC(2)); break;
+                case 3: terms(BLS381_IC(0), BLS381_IC(3)); break;
+                case 4: terms(BLS381_IC(0), BLS381_IC(4)); break;
+                case 5: terms(BLS381_IC(0), BLS381_IC(4)); terms(BLS381_IC(4), BLS381_IC(1)); break;
+                case 6: terms(BLS381_IC(0), BLS381_IC(4)); terms(BLS381_IC(4), BLS381_IC(2)); break;
+                default: terms(BLS381_IC(0), BLS381_IC(4)); terms(BLS381_IC(4), BLS381_IC(3)); break;
             }
+#undef BLS381_IC
             if (flags & 2u) reduce28(acc);  // sweeps as well
             else if (flags) normalise28(acc);
             lds_store(dst, acc);
@@ -185,7 +263,10 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                     v[12] = t.x; v[13] = t.y;
                 } else if (kind == CK_CONST) {
                     const uint4* p = A.consts + (size_t)src * 4;
-                    uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+                    uint4 v0 = p[0], v1 = p[1], v2 = p[2];
+                    const uint2* pt = reinterpret_cast<const uint2*>(p + 3);
+                    asm volatile("" : "+v"(pt));
+                    uint2 v3 = *pt;
                     unpack3(v0, v1, v2, v);
                     v[12] = v3.x; v[13] = v3.y;
                 } else {
@@ -215,6 +296,20 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                     p[A.npad] = make_uint4(l[4], l[5], l[6], l[7]);
                     p[2 * (size_t)A.npad] = make_uint4(l[8], l[9], l[10], l[11]);
                 }
+            }
+        }
+        if (carries && (hx & (1u << 23))) {
+            // every path consumes the loaded registers here (see the copy step)
+            asm volatile("" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]), "+v"(pf[6]),
+                              "+v"(pf[7]), "+v"(pf[8]), "+v"(pf[9]), "+v"(pf[10]), "+v"(pf[11]), "+v"(pf[12]), "+v"(pf[13]));
+            if (lane_on && (dw & (1u << 16))) {
+                if (((dw >> 7) & 3u) == CK_IN) {
+                    u32 l[12];
+#pragma unroll
+                    for (int i = 0; i < 12; i++) l[i] = pf[i];
+                    unpack28(l, pf);
+                }
+                lds_store(dw & 0x7fu, pf);
             }
         }
       }

@@ -151,12 +151,42 @@ def run_program(prog, gin, strict=True):
     for s in range(prog["nsteps"]):
         typ, mt = hd[2 * s], hd[2 * s + 1]
         writes = []
+        late = []                                   # carried fills: LDS written after the step's results
+        if typ != ST_COPY:
+            carried = [(ds[(s * K + r) * 8 + 5], ds[(s * K + r) * 8 + 6], ds[(s * K + r) * 8 + 7]) for r in range(K)]
+            # w[9] = low half of dword 5 ... the descriptor dwords are hdr, w0|w1<<16, w2|w3<<16, ...
+            any_fill = any_spill = False
+            stored = set()
+            for d5, d6, d7 in carried:               # the fills' loads first
+                w9, w10 = d5 >> 16, d6 & 0xffff
+                if w9 & 0x8000:
+                    any_fill = True
+                    kind, src = w10 >> 12, w10 & 0xfff
+                    assert src < 128
+                    if kind == CK_IN:
+                        val = to_digits(gin[src])
+                    elif kind == CK_FILL:
+                        val = gtmp[src]
+                        stored.add(src)
+                    else:
+                        assert kind == CK_CONST
+                        val = consts[src]
+                    late.append((w9 & 0x7fff, val))
+            for d5, d6, d7 in carried:               # then the spills: LDS as the step finds it
+                w11, w12 = d6 >> 16, d7 & 0xffff
+                if w11 & 0x8000:
+                    any_spill = True
+                    assert lds[w11 & 0x7fff] is not None and w12 < 128
+                    assert w12 not in stored, "a step fills what it spills"
+                    gtmp[w12] = lds[w11 & 0x7fff]
+            assert bool(mt & 0x10000) == any_fill and bool(mt & 0x20000) == any_spill, "step-wide carry flags are wrong"
         for r in range(K):
             d = ds[(s * K + r) * 8:(s * K + r) * 8 + 8]
             if not (d[0] & 1):
                 if typ != ST_COPY:  # idle lanes run branch-free on ZERO and store to TRASH
                     assert d[1] & 0xffff == prog["lds_slots"] - 1
-                    assert all(x == (prog["lds_slots"] - 2) * 0x10001 for x in d[2:]) and d[1] >> 16 == prog["lds_slots"] - 2
+                    zero = prog["lds_slots"] - 2
+                    assert all(x == zero * 0x10001 for x in d[2:5]) and d[1] >> 16 == zero and d[5] & 0xffff == zero
                 continue
             w = []
             for x in d[1:]:
@@ -218,6 +248,9 @@ def run_program(prog, gin, strict=True):
                 else:
                     assert lds[w[1]] is not None
                     writes.append(("out", w[0], canon(lds[w[1]])))
+        for idx, v in late:
+            assert all(not (w == "lds" and i == idx) for w, i, _ in writes), "carried fill lands on a result of its carrier"
+            writes.append(("lds", idx, v))
         seen = set()
         for where, idx, v in writes:
             assert (where, idx) not in seen, "two lanes write one slot in one step"
