@@ -24,7 +24,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "oracle", "py"))
 
 BATCH = 65536
-# Algorithmic work (BASELINE.md / DESIGN.md): Fp-multiplication-equivalents x 300 MAC (12-limb CIOS)
+# Algorithmic work: Fp-multiplication-equivalents of the reference's formulas x 300 multiply-accumulates
+# (12 x 32-bit limbs: 144 for the product, 156 for the Montgomery reduction)
 W_PAIR = 15260 * 300          # whole pairing
 W_MILLER = 7141 * 300         # G2 line precompute + Miller loop
 W_FE2 = (8119 - 460 - 75) * 300   # final exponentiation minus the Fp inversion chain and the norm part
@@ -135,7 +136,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32x12 Montgomery limbs (integer)",
+            "dtype": "integer: 14 signed 28-bit digits per Fp value in u32 (64-bit column accumulators); 12 x u32 "
+                     "Montgomery limbs at the boundary",
             "data": "synthetic: 256 seeded G1 x 256 seeded G2 multiples of the generators -> 65,536 distinct pairs per GPU",
             "config": {"workload": "65,536 independent pairings (Miller loop + final exponentiation) per GPU per step, "
                                    "bit-exact vs the CPU oracle (BASELINE configs[1])",
