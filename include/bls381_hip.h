@@ -128,6 +128,11 @@ int bls381_debug_program(const char* which, int lanes_per_group, int lds_slots, 
  * (out_plain). */
 int bls381_debug_fp_mul(bls381_ctx*, const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out,
                         uint32_t* out_plain);
+/* Element-wise Fq inversion of n <= 65,536 values in boundary form (12 x u32, Montgomery 2^384):
+ * out = a^-1 in the same form, 0 for a = 0 with is_zero[i] = 1.  The inversion kernel that
+ * Fq12::inverse (/root/reference/src/native/final_exponentiation.rs:9, through ark-ff) bottoms out
+ * in, exposed for direct testing. */
+int bls381_debug_fp_inverse(bls381_ctx*, const uint32_t* a, size_t n, uint32_t* out, uint8_t* is_zero);
 /* The interpreter's constant table: C_COUNT rows of 16 u32 (14 digits of 28 bits, zero padded). */
 int bls381_debug_constants(uint32_t* out, size_t capacity_fp);
 /* Per-step-kind shader-clock accounting of program `which` ("miller", "fe2", ...) run over n

@@ -55,6 +55,7 @@ _sig("bls381_debug_program", C.c_int, C.c_char_p, C.c_int, C.c_int, u32p, u32p, 
 _sig("bls381_debug_constants", C.c_int, u32p, C.c_size_t)
 _sig("bls381_debug_profile", C.c_int, C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64))
 _sig("bls381_debug_fp_mul", C.c_int, ctxp, u32p, u32p, C.c_size_t, u32p, u32p)
+_sig("bls381_debug_fp_inverse", C.c_int, ctxp, u32p, C.c_size_t, u32p, C.POINTER(C.c_uint8))
 _sig("bls381_last_timing", C.c_int, ctxp, C.POINTER(C.c_float))
 _sig("bls381_calibrate_mac_rate", C.c_int, ctxp, C.POINTER(C.c_double))
 
@@ -66,7 +67,7 @@ EXPORTED = [
     "bls381_easy_part_batch", "bls381_hard_part_batch", "bls381_frobenius_batch", "bls381_fq12_mul_batch",
     "bls381_fq12_inverse_limbs_batch", "bls381_pairing_witness_rows", "bls381_pairing_witness_kinds",
     "bls381_pairing_witness_batch", "bls381_pairing_batch_dev", "bls381_miller_loop_batch_dev",
-    "bls381_final_exp_batch_dev", "bls381_debug_program", "bls381_debug_constants", "bls381_debug_profile", "bls381_debug_fp_mul", "bls381_last_timing",
+    "bls381_final_exp_batch_dev", "bls381_debug_program", "bls381_debug_constants", "bls381_debug_profile", "bls381_debug_fp_mul", "bls381_debug_fp_inverse", "bls381_last_timing",
     "bls381_calibrate_mac_rate",
 ]
 

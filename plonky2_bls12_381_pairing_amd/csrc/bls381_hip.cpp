@@ -813,6 +813,30 @@ extern "C" int bls381_debug_fp_mul(bls381_ctx* c, const uint32_t* a, const uint3
     return 0;
 }
 
+// element-wise Fp inversion in boundary form (x R -> x^-1 R; 0 -> 0 with is_zero set): the inversion
+// kernel of the final exponentiation on its own
+extern "C" int bls381_debug_fp_inverse(bls381_ctx* c, const uint32_t* a, size_t n, uint32_t* out, uint8_t* is_zero) {
+    CTX_GUARD(c);
+    if (n == 0) return 0;
+    if (!a || !out || !is_zero) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    if (n > CHUNK) return fail(BLS381_ERR_INVALID, "at most 65,536 elements per call");
+    int rc;
+    int npad = pad_elems(n);
+    if ((rc = h2d(c, c->user_in, a, n * 48))) return rc;
+    HIPCHK(c->bufA.ensure(soa_bytes(1, npad)));
+    HIPCHK(c->zflags.ensure(n));
+    HIPCHK(c->user_out.ensure(n * 48));
+    if ((rc = pack(c, c->user_in.p, c->bufA.p, (int)n, npad, 1, 0))) return rc;
+    hipLaunchKernelGGL(fp_inverse_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, (uint4*)c->bufA.p, 0,
+                       (int)n, npad, c->d_consts, (uint8_t*)c->zflags.p);
+    HIPCHK(hipGetLastError());
+    if ((rc = unpack(c, c->bufA.p, c->user_out.p, (int)n, npad, 1, 0))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->user_out.p, n * 48, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(is_zero, c->zflags.p, n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // sustained v_mad_u64_u32 rate: 8 independent accumulators per lane, 8 waves per SIMD
 __global__ void mac_rate_kernel(u32* out, u32 seed, int iters) {
     u32 a = seed + threadIdx.x, b = seed * 3 + blockIdx.x;

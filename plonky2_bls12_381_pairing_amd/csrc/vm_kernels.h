@@ -376,14 +376,64 @@ __global__ void tree_pack_kernel(const uint4* src, uint4* dst, const uint4* cons
     }
 }
 
-// In-place x <- x^(p-2) on slot `slot` of a slot array, one lane per element (Fermat inversion by
-// left-to-right square-and-multiply; 0 maps to 0 and is reported through is_zero).
+// In-place modular inversion of slot `slot` of a slot array (boundary form: x R -> x^-1 R, R = 2^384),
+// one lane per element; 0 maps to 0 and is reported through is_zero.
+//
+// Bernstein-Yang division steps ("safegcd", delta variant) in the arrangement of libsecp256k1's
+// modinv32, sized for the 381-bit modulus: f, g, d, e are 13 signed limbs of 30 bits; each round runs
+// 30 division steps on the low 32 bits of f and g, collecting a 2x2 transition matrix with 31-bit
+// entries, then applies it to (f, g) exactly and to (d, e) modulo p.  37 rounds = 1,110 steps cover
+// the proven bound floor((49 * 381 + 57) / 17) = 1,101, after which g = 0, f = +-1 and d = +-1/x.
+// About 33,000 instructions per element, against 400,000 for the Fermat chain x^(p-2).
+namespace inv30 {
+enum { NL = 13, ROUNDS = 37 };
+#define BLS381_M30 0x3fffffff
+#define BLS381_P30_LIMBS                                                                                          \
+    { 0x3fffaaab, 0x27fbffff, 0x153ffffb, 0x2affffac, 0x30f6241e, 0x034a83da, 0x112bf673, 0x12e13ce1, 0x2cd76477, \
+      0x1ed90d2e, 0x29a4b1ba, 0x3a8e5ff9, 0x001a0111 }
+#define BLS381_PINV30 0x00030003u  // p^-1 mod 2^30
+
+// [a; b] <- ([[u, v], [q, r]] [a; b] + [ma; mb] p) / 2^30, exact; WITH_P = false drops the p terms
+template <bool WITH_P>
+__device__ __forceinline__ void apply(int* a, int* b, int u, int v, int q, int r, int ma, int mb) {
+    const int P[NL] = BLS381_P30_LIMBS;
+    int64_t ca = (int64_t)u * a[0] + (int64_t)v * b[0];
+    int64_t cb = (int64_t)q * a[0] + (int64_t)r * b[0];
+    if (WITH_P) {
+        // choose the multiples of p that clear the low 30 bits
+        ma -= (int)((BLS381_PINV30 * (u32)ca + (u32)ma) & BLS381_M30);
+        mb -= (int)((BLS381_PINV30 * (u32)cb + (u32)mb) & BLS381_M30);
+        ca += (int64_t)P[0] * ma;
+        cb += (int64_t)P[0] * mb;
+    }
+    ca >>= 30;
+    cb >>= 30;
+#pragma unroll
+    for (int i = 1; i < NL; i++) {
+        ca += (int64_t)u * a[i] + (int64_t)v * b[i];
+        cb += (int64_t)q * a[i] + (int64_t)r * b[i];
+        if (WITH_P) {
+            ca += (int64_t)P[i] * ma;
+            cb += (int64_t)P[i] * mb;
+        }
+        a[i - 1] = (int)((u32)ca & BLS381_M30);
+        b[i - 1] = (int)((u32)cb & BLS381_M30);
+        ca >>= 30;
+        cb >>= 30;
+    }
+    a[NL - 1] = (int)ca;
+    b[NL - 1] = (int)cb;
+}
+}  // namespace inv30
+
 __global__ __launch_bounds__(64) void fp_inverse_kernel(uint4* soa, int slot, int n, int npad, const uint4* consts,
                                                         uint8_t* is_zero) {
-    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    uint4* p = soa + ((size_t)slot * 3) * npad + e;
-    u32 a[12], r[12];
+    using namespace inv30;
+    (void)consts;
+    long el = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (el >= n) return;
+    uint4* p = soa + ((size_t)slot * 3) * npad + el;
+    u32 a[12];
     {
         uint4 v0 = p[0], v1 = p[npad], v2 = p[2 * (size_t)npad];
         unpack3(v0, v1, v2, a);
@@ -391,28 +441,81 @@ __global__ __launch_bounds__(64) void fp_inverse_kernel(uint4* soa, int slot, in
     u32 nz = 0;
 #pragma unroll
     for (int i = 0; i < 12; i++) nz |= a[i];
-    if (is_zero) is_zero[e] = (nz == 0);
-    {
-        uint4 v0 = consts[C_ONE * 3], v1 = consts[C_ONE * 3 + 1], v2 = consts[C_ONE * 3 + 2];
-        unpack3(v0, v1, v2, r);
-    }
-    const u32 E[12] = {0xffffaaa9u, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
-                       0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};  // p - 2
-    for (int w = 11; w >= 0; w--) {
-        const u32 ew = E[w];
-        for (int b = 31; b >= 0; b--) {
-            u32 t[12];
-            fp_mul(r, r, t);
-            if ((ew >> b) & 1u) fp_mul(t, a, r);
-            else {
+    if (is_zero) is_zero[el] = (nz == 0);
+
+    int f[NL] = BLS381_P30_LIMBS, g[NL], d[NL], e[NL];
 #pragma unroll
-                for (int i = 0; i < 12; i++) r[i] = t[i];
-            }
-        }
+    for (int i = 0; i < NL; i++) {
+        const int bit = 30 * i, w = bit >> 5, s = bit & 31;
+        u32 v = w < 12 ? a[w] >> s : 0u;
+        if (s > 2 && w + 1 < 12) v |= a[w + 1] << (32 - s);
+        g[i] = (int)(v & BLS381_M30);
+        d[i] = 0;
+        e[i] = i == 0 ? 1 : 0;
     }
-    p[0] = make_uint4(r[0], r[1], r[2], r[3]);
-    p[npad] = make_uint4(r[4], r[5], r[6], r[7]);
-    p[2 * (size_t)npad] = make_uint4(r[8], r[9], r[10], r[11]);
+    int delta = 1;
+#pragma unroll 1
+    for (int round = 0; round < ROUNDS; round++) {
+        // 30 division steps on the low 32 bits: 2^30 [f'; g'] = [[u, v], [q, r]] [f; g]
+        u32 f0 = (u32)f[0] | ((u32)f[1] << 30), g0 = (u32)g[0] | ((u32)g[1] << 30);
+        int u = 1, v = 0, q = 0, r = 1;
+#pragma unroll
+        for (int i = 0; i < 30; i++) {
+            // delta > 0 and g odd: (delta, f, g) <- (-delta, g, -f), rows swapped likewise
+            const u32 c1 = (u32)((-delta) >> 31) & (0u - (g0 & 1u));
+            const u32 tf = f0, tg = g0;
+            f0 = (tg & c1) | (tf & ~c1);
+            g0 = ((0u - tf) & c1) | (tg & ~c1);
+            const int tu = u, tv = v;
+            u = (q & (int)c1) | (tu & (int)~c1);
+            v = (r & (int)c1) | (tv & (int)~c1);
+            q = ((-tu) & (int)c1) | (q & (int)~c1);
+            r = ((-tv) & (int)c1) | (r & (int)~c1);
+            delta = (delta ^ (int)c1) - (int)c1;
+            // g odd: g += f, second row += first
+            const u32 c2 = 0u - (g0 & 1u);
+            g0 += f0 & c2;
+            q += u & (int)c2;
+            r += v & (int)c2;
+            delta += 1;
+            g0 >>= 1;
+            u <<= 1;
+            v <<= 1;
+        }
+        // (d, e) stay in (-2p, p): a negative input counts p once more
+        const int sd = d[NL - 1] >> 31, se = e[NL - 1] >> 31;
+        apply<true>(d, e, u, v, q, r, (u & sd) + (v & se), (q & sd) + (r & se));
+        apply<false>(f, g, u, v, q, r, 0, 0);
+    }
+    // d * sign(f) into [0, p)
+    const int P[NL] = BLS381_P30_LIMBS;
+    const int sign = f[NL - 1] >> 31;
+    int add = d[NL - 1] >> 31;  // (-2p, p) -> (-p, p)
+#pragma unroll
+    for (int i = 0; i < NL; i++) d[i] = ((d[i] + (P[i] & add)) ^ sign) - sign;
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) { d[i + 1] += d[i] >> 30; d[i] &= BLS381_M30; }
+    add = d[NL - 1] >> 31;  // (-p, p) -> [0, p)
+#pragma unroll
+    for (int i = 0; i < NL; i++) d[i] += P[i] & add;
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) { d[i + 1] += d[i] >> 30; d[i] &= BLS381_M30; }
+    // 13 x 30 bits -> 12 x 32, then (x R)^-1 * R^3 / R = x^-1 R
+    u32 x[12], res[12];
+#pragma unroll
+    for (int w = 0; w < 12; w++) {
+        const int bit = 32 * w, i = bit / 30, s = bit - 30 * i;
+        u32 v = (u32)d[i] >> s;
+        v |= (u32)d[i + 1] << (30 - s);
+        if (60 - s < 32 && i + 2 < NL) v |= (u32)d[i + 2] << (60 - s);
+        x[w] = v;
+    }
+    const u32 R3[12] = {0xd94ca1e0u, 0xed48ac6bu, 0x03a7adf8u, 0x315f831eu, 0x615e29ddu, 0x9a53352au,
+                        0x921e1761u, 0x34c04e5eu, 0x65724728u, 0x2512d435u, 0x91755d4du, 0x0aa63460u};  // R^3 mod p
+    fp_mul(x, R3, res);
+    p[0] = make_uint4(res[0], res[1], res[2], res[3]);
+    p[npad] = make_uint4(res[4], res[5], res[6], res[7]);
+    p[2 * (size_t)npad] = make_uint4(res[8], res[9], res[10], res[11]);
 }
 
 }  // namespace bls381

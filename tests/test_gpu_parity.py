@@ -268,3 +268,26 @@ def test_fp_mul_kernel_against_big_integers(ctx):
     want = np.array([R.fq_to_u32_limbs(x * y * rinv % R.P) for x, y in pairs], dtype=np.uint32)
     assert np.array_equal(out, want)
     assert np.array_equal(plain, want)
+
+
+def test_fp_inverse_kernel_against_big_integers(ctx):
+    """The division-step inversion on 2^16 values: edge cases (0, R mod p = one, p-1, 2, small and
+    high-bit patterns) and random residues, against Python's modular inverse; zero is flagged."""
+    import ctypes as C
+    import random
+    from plonky2_bls12_381_pairing_amd import _lib
+    rng = random.Random(1234)
+    edge = [0, 1, 2, 3, R.P - 1, R.P - 2, R.MONT_R, (R.P + 1) // 2, 1 << 380, (1 << 380) - 1, 0xffffffff, 1 << 32,
+            1 << 352, (1 << 381) - 1 - ((1 << 381) - 1 >= R.P) * (1 << 200)]
+    vals = [v % R.P for v in edge] + [1 << k for k in range(381)] + [R.P - (1 << k) for k in range(380)]
+    vals += [rng.randrange(R.P) for _ in range(65536 - len(vals))]
+    n = len(vals)
+    a = np.array([R.fq_to_u32_limbs(x) for x in vals], dtype=np.uint32)
+    out = np.empty_like(a)
+    flags = np.zeros(n, dtype=np.uint8)
+    _lib.check(_lib.lib.bls381_debug_fp_inverse(ctx.handle, a.ctypes.data_as(_lib.u32p), n, out.ctypes.data_as(_lib.u32p),
+                                                flags.ctypes.data_as(C.POINTER(C.c_uint8))))
+    r2 = pow(1 << 384, 2, R.P)      # (x R)^-1 R^2 = x^-1 R
+    want = np.array([R.fq_to_u32_limbs(pow(x, -1, R.P) * r2 % R.P if x else 0) for x in vals], dtype=np.uint32)
+    assert np.array_equal(out, want)
+    assert flags.tolist() == [int(x == 0) for x in vals]

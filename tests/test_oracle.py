@@ -142,3 +142,14 @@ def test_c_oracle_matches_python():
             assert (H.u64_to_fq(cf[k, j, 0]), H.u64_to_fq(cf[k, j, 1])) == ref[k][j]
     with pytest.raises(ZeroDivisionError):
         CO.final_exp_batch(np.zeros((1, 72), dtype=np.uint64))
+
+
+def test_divstep_inversion_model():
+    """The limb-accurate model of the GPU's division-step inversion (register widths asserted inside)
+    agrees with Python's modular inverse."""
+    import random
+    import divstep_model as D
+    rng = random.Random(11)
+    xs = [0, 1, 2, D.P - 1, D.P - 2, (D.P + 1) // 2, 1 << 380] + [rng.randrange(D.P) for _ in range(300)]
+    for x in xs:
+        assert D.modinv(x) == (pow(x, -1, D.P) if x else 0)
