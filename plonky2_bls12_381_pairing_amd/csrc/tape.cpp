@@ -154,29 +154,41 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
     // ---- bound analysis.  Values are lazily reduced signed-digit numbers:
     //   |value| < vb * p                 (value bound)
     //   |digit| <= db * 2^28             (digit bound; the top digit follows from vb)
-    //   product / two-product sum: needs  sum of vb products <= 2500  (2^392 / p = 2520.2)
-    //                              and    sum of db products <= 8     (64-bit column accumulator);
-    //                              result vb = 2, db = 1
+    //   product / two-product sum: result vb = 1 + ceil(sum of vb products / 2520)  (2^392 / p = 2520.2),
+    //                              db = 1; needs sum of db products <= 8  (64-bit column accumulator)
     //   sum:                       vb and db add up; db <= 7 (32-bit digits)
     //   sum + carry sweep:         db = 1
     //   sum + sweep + reduction:   vb = 2, db = 1
     // A sum gets a sweep or a reduction only when a consumer's limit demands it.
-    const int MUL_VB_LIMIT = 2500, MUL_DB_LIMIT = 8, SUM_VB_LIMIT = 2047, SUM_DB_LIMIT = 7;
+    // (a product of larger operands is still exact, its result is just wider: |result| <
+    // (1 + sum / 2520) p.  The hard limits are the 28-bit top digit of an operand, vb <= 2047, and the
+    // same for results.)
+    const long MUL_VB_LIMIT = 2520L * 2046, MUL_DB_LIMIT = 8;
+    const int SUM_VB_LIMIT = 2047, SUM_DB_LIMIT = 7;
     std::vector<int> vb(n, 1), db(n, 1);
     std::vector<char> lin_norm(n, 0), lin_reduce(n, 0);
     int n_reduce = 0, n_norm = 0;
     // picks the sum among `cands` with the largest bound that has not been treated yet
+    std::vector<char> narrow(n, 0);  // products whose result must stay below 2p: their own operands get reduced
     auto widest = [&](const std::vector<int>& cands, const std::vector<int>& bnd, const std::vector<char>& done_flag) {
         int best = -1;
-        for (int x : cands)
-            if (N[x].kind == NK_LIN && !done_flag[x] && !lin_reduce[x] && (best < 0 || bnd[x] > bnd[best])) best = x;
+        for (int x : cands) {
+            const bool sum_ok = N[x].kind == NK_LIN && !done_flag[x] && !lin_reduce[x];
+            const bool mul_ok = (N[x].kind == NK_FMUL || N[x].kind == NK_DOT2) && !narrow[x] && bnd[x] > 2 && &bnd == &vb;
+            if ((sum_ok || mul_ok) && (best < 0 || bnd[x] > bnd[best])) best = x;
+        }
         if (best < 0) throw std::runtime_error("scheduler: operand bounds cannot be met (" + name + ")");
         return best;
+    };
+    // marks the chosen node: a sum gets the flag, a wide product is made narrow instead
+    auto treat = [&](int x, std::vector<char>& flag, int& counter) {
+        if (N[x].kind == NK_LIN) { flag[x] = 1; counter++; }
+        else narrow[x] = 1;
     };
     // Sums with several consumers are treated eagerly once their bounds pass a threshold: one sweep
     // or reduction there spares each consumer (and their consumers) its own.
     auto env_int = [](const char* nm, int dflt) { const char* v = getenv(nm); return v ? atoi(v) : dflt; };
-    const int VB_EAGER = env_int("BLS381_VB_EAGER", 12), DB_EAGER = env_int("BLS381_DB_EAGER", 3);
+    const int VB_EAGER = env_int("BLS381_VB_EAGER", 400), DB_EAGER = env_int("BLS381_DB_EAGER", 3);
     for (bool again = true; again;) {
         again = false;
         for (int i = 0; i < n && !again; i++) {
@@ -187,22 +199,23 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                 case NK_FMUL:
                 case NK_DOT2: {
                     std::vector<int> ops{nd.a, nd.b};
-                    int sv = vb[nd.a] * vb[nd.b], sd = db[nd.a] * db[nd.b];
+                    long sv = (long)vb[nd.a] * vb[nd.b];
+                    int sd = db[nd.a] * db[nd.b];
                     if (nd.kind == NK_DOT2) {
                         ops.push_back(nd.c); ops.push_back(nd.d);
-                        sv += vb[nd.c] * vb[nd.d]; sd += db[nd.c] * db[nd.d];
+                        sv += (long)vb[nd.c] * vb[nd.d]; sd += db[nd.c] * db[nd.d];
                     }
-                    if (sv > MUL_VB_LIMIT) { int x = widest(ops, vb, lin_reduce); lin_reduce[x] = 1; n_reduce++; again = true; }
-                    else if (sd > MUL_DB_LIMIT) { int x = widest(ops, db, lin_norm); lin_norm[x] = 1; n_norm++; again = true; }
-                    vb[i] = 2; db[i] = 1;
+                    if (sv > (narrow[i] ? 2500L : MUL_VB_LIMIT)) { treat(widest(ops, vb, lin_reduce), lin_reduce, n_reduce); again = true; }
+                    else if (sd > MUL_DB_LIMIT) { treat(widest(ops, db, lin_norm), lin_norm, n_norm); again = true; }
+                    vb[i] = 1 + (int)((sv + 2519) / 2520); db[i] = 1;
                     break;
                 }
                 case NK_LIN: {
                     int sv = 0, sd = 0;
                     std::vector<int> ops;
                     for (auto& t : nd.terms) { sv += vb[t.node]; sd += db[t.node]; ops.push_back(t.node); }
-                    if (sv > SUM_VB_LIMIT) { int x = widest(ops, vb, lin_reduce); lin_reduce[x] = 1; n_reduce++; again = true; }
-                    else if (sd > SUM_DB_LIMIT) { int x = widest(ops, db, lin_norm); lin_norm[x] = 1; n_norm++; again = true; }
+                    if (sv > SUM_VB_LIMIT) { treat(widest(ops, vb, lin_reduce), lin_reduce, n_reduce); again = true; }
+                    else if (sd > SUM_DB_LIMIT) { treat(widest(ops, db, lin_norm), lin_norm, n_norm); again = true; }
                     else if (succ[i].size() >= 2) {
                         if (sv >= VB_EAGER && !lin_reduce[i]) { lin_reduce[i] = 1; n_reduce++; }
                         else if (sd >= DB_EAGER && !lin_norm[i] && !lin_reduce[i]) { lin_norm[i] = 1; n_norm++; }
@@ -215,6 +228,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                     // a store handles (-p, 2p) with normalised digits: what multiplications produce
                     if (N[nd.a].kind != NK_FMUL && N[nd.a].kind != NK_DOT2)
                         throw std::runtime_error("scheduler: stored value must come from a multiplication");
+                    if (vb[nd.a] > 2 && !narrow[nd.a]) { narrow[nd.a] = 1; again = true; }
                     break;
             }
         }
@@ -382,7 +396,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                 else t = n_tmp++;
                 tmp_of[o] = t;
                 if (for_fill) {
-                    if (carrier_prev && !from_prev && prev_nspill < K) {
+                    if (carrier_prev && !from_prev && prev_nspill < K && t < 128) {  // 7-bit fields in the packed descriptor
                         OpDesc& d = P.descs[prev_idx * K + prev_nspill++];
                         d.w[11] = (uint16_t)(victim | 0x8000); d.w[12] = (uint16_t)t;
                         prev_spilled.insert(t);
@@ -394,7 +408,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                         how = 2;
                     }
                 } else {
-                    if (carrier_cur && (int)cur_spills.size() < K) { cur_spills.push_back({victim, t}); how = 1; }
+                    if (carrier_cur && (int)cur_spills.size() < K && t < 128) { cur_spills.push_back({victim, t}); how = 1; }
                     else { spills_b.push_back(CopyOp{CK_SPILL, t, victim}); how = 2; }
                 }
             } else if (from_prev) {

@@ -142,7 +142,10 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                       // the loaded registers, and so wait for the loads, right where they are issued
         u32 dw = 0;   // the descriptor word of the carried copies, fetched only by steps that carry any
         const bool carries = type != ST_COPY && (hx & (3u << 23));
-        if (carries) dw = (u32)__builtin_amdgcn_ds_bpermute((j * K + role) * 4, (int)cur.w);
+        if (carries) {
+            dw = (u32)__builtin_amdgcn_ds_bpermute((j * K + role) * 4, (int)cur.w);
+            asm volatile("" : "+v"(dw));  // nothing derived from dw is computed (and waited for) by steps that carry nothing
+        }
         if (carries && (hx & (1u << 23))) {
             // a fill may read what a spill of an earlier step wrote: drain the wave's stores first
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -194,9 +194,9 @@ def run_program(prog, gin, strict=True):
             if typ == ST_FMUL:
                 a, b = lds[w[1]], lds[w[2]]
                 assert a is not None and b is not None, "FMUL reads an empty slot"
-                assert abs(value(a) * value(b)) < MUL_LIMIT * P * P, "FMUL operands exceed the Montgomery bound"
+                assert abs(value(a)) < 2048 * P and abs(value(b)) < 2048 * P, "FMUL operand too wide"
                 out = mulacc(a, b)
-                assert (value(out) << RBITS) % P == value(a) * value(b) % P and -P < value(out) < 2 * P
+                assert (value(out) << RBITS) % P == value(a) * value(b) % P and abs(value(out)) < 2048 * P
                 writes.append(("lds", w[0], out))
             elif typ == ST_DOT2:
                 a, b = lds[w[1]], lds[w[2]]
@@ -207,9 +207,9 @@ def run_program(prog, gin, strict=True):
                 if d[0] & 4:
                     d2 = [s32(-x) for x in d2]
                 t = value(a) * value(b) + value(c2) * value(d2)
-                assert abs(value(a) * value(b)) + abs(value(c2) * value(d2)) < MUL_LIMIT * P * P, "DOT2 operands exceed the Montgomery bound"
+                assert all(abs(value(x)) < 2048 * P for x in (a, b, c2, d2)), "DOT2 operand too wide"
                 out = mulacc(a, b, c2, d2)
-                assert (value(out) << RBITS) % P == t % P and -P < value(out) < 2 * P
+                assert (value(out) << RBITS) % P == t % P and abs(value(out)) < 2048 * P
                 writes.append(("lds", w[0], out))
             elif typ == ST_LIN:
                 nt = (d[0] >> 8) & 0xff
