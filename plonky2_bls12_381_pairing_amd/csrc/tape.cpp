@@ -239,7 +239,9 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
     P.n_reduce = n_reduce; P.n_norm = n_norm;
 
     // ---- pass 1: list scheduling into K-wide single-class steps
-    const int WINDOW = 600;
+    auto env_int2 = [](const char* nm, int dflt) { const char* v = getenv(nm); return v ? atoi(v) : dflt; };
+    const int WINDOW = env_int2("BLS381_WINDOW", 600);
+    const bool split_mul = env_int2("BLS381_SPLIT_MUL", 0) != 0;
     std::vector<char> done(n, 0);
     std::vector<int> ready;  // nodes whose predecessors all sit in closed steps
     for (int i = 0; i < n; i++) if (npred[i] == 0) ready.push_back(i);
@@ -262,6 +264,14 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
             if (prio[a] != prio[b]) return prio[a] > prio[b];
             return a < b;
         });
+        if (cls == OC_FMUL && split_mul) {
+            // a single product riding in a two-product step costs a two-product: keep the kinds apart
+            // whenever one of them fills a step on its own
+            std::vector<int> singles, doubles;
+            for (int x : c) (N[x].kind == NK_FMUL ? singles : doubles).push_back(x);
+            if ((int)doubles.size() >= K) c.swap(doubles);
+            else if ((int)singles.size() >= K) c.swap(singles);
+        }
         if ((int)c.size() > K) {
             if (cls == OC_LIN) {
                 // keep the most urgent op, fill the step with the ops closest to it in cost

@@ -231,6 +231,27 @@ def test_full_batch_65536_against_c_oracle_and_bilinearity(ctx, CO):
     assert all(np.array_equal(prod[i], one) for i in range(m))
 
 
+def test_batch_spanning_two_chunks(ctx, CO):
+    """A batch larger than the library's 65,536-element working chunk (maximum-size edge): elements on
+    both sides of the chunk boundary and the ragged tail against the CPU oracle, and the tail chunk
+    equal to the same inputs run as a batch of their own."""
+    n = 65536 + 777
+    base = 32
+    ps, qs = H.random_pairs(base, 777)
+    g1b, g2b = H.g1_array(ps), H.g2_array(qs)
+    idx_p = (np.arange(n) * 5 + 1) % base
+    idx_q = (np.arange(n) // 3) % base
+    g1, g2 = g1b[idx_p], g2b[idx_q]
+    out = ctx.pairing_batch(g1, g2)
+    probe = np.array([0, 1, 65535, 65536, 65537, 65536 + 64, n - 2, n - 1])
+    assert np.array_equal(out[probe], CO.pairing_batch(g1[probe], g2[probe]))
+    assert np.array_equal(out[65536:], ctx.pairing_batch(g1[65536:], g2[65536:]))
+    ml = ctx.miller_loop_batch(g1, g2)
+    fe = ctx.final_exponentiation_batch(ml[65500:65600])
+    fe = fe[0] if isinstance(fe, tuple) else fe
+    assert np.array_equal(fe, out[65500:65600])
+
+
 def test_pairing_witness_trace(ctx):
     """Every row of the witness trace (canonical 12 x u32 limbs) against the CPU replay of the
     circuit's builder calls, for three proofs."""
