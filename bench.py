@@ -163,7 +163,7 @@ def main():
             t1 = time.perf_counter()
             CO.pairing_batch(g1[probe], g2[probe])                  # warms the threads, sizes the sample
             rate = len(probe) / (time.perf_counter() - t1)
-            nsamp = int(min(BATCH, max(len(probe), rate * 12.0)))   # about 12 s of CPU work
+            nsamp = int(min(BATCH, max(len(probe), rate * 22.0)))   # 10-20 s of CPU work (the cold probe reads low)
             idx = np.arange(nsamp) * 37 % BATCH
             t1 = time.perf_counter()
             CO.pairing_batch(g1[idx], g2[idx])
