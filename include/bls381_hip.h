@@ -135,6 +135,27 @@ int bls381_debug_fp_mul(bls381_ctx*, const uint32_t* a, const uint32_t* b, size_
 int bls381_debug_fp_inverse(bls381_ctx*, const uint32_t* a, size_t n, uint32_t* out, uint8_t* is_zero);
 /* The interpreter's constant table: C_COUNT rows of 16 u32 (14 digits of 28 bits, zero padded). */
 int bls381_debug_constants(uint32_t* out, size_t capacity_fp);
+/* ---- one G2 point against many G1 points ------------------------------------------------------
+ * G2Prepared (/root/reference/src/native/miller_loop.rs:13-16, 90-119) holds the 68 line coefficients
+ * of Q so that they are computed once and reused by every Miller loop against that Q (:139-156).
+ * bls381_g2_prepared_create computes them on the device (same program as bls381_g2_prepare_batch)
+ * and keeps them there in the kernels' internal number format; g2 = {x.c0, x.c1, y.c0, y.c1} as
+ * 24 u64, ignored when q_is_infinity != 0 (G2Prepared::infinity: every pair is then skipped and
+ * yields one).  The handle belongs to the context's device; destroy it before the context. */
+typedef struct bls381_g2_prepared bls381_g2_prepared;
+int bls381_g2_prepared_create(bls381_ctx*, const uint64_t* g2, int q_is_infinity, bls381_g2_prepared** out);
+void bls381_g2_prepared_destroy(bls381_g2_prepared*);
+/* multi_miller_loop_native([p_i], [q]) for each i (conjugated, before the final exponentiation;
+ * miller_loop.rs:121-162 with b = the one prepared point), and native_pairing([p_i], [q])
+ * (pairing.rs:8-13).  p_is_infinity: optional byte per element, non-zero = P_i is the point at
+ * infinity (the pair is skipped: result one).  The _dev form takes device pointers. */
+int bls381_miller_loop_fixed_q_batch(bls381_ctx*, const bls381_g2_prepared* q, const uint64_t* g1,
+                                     const uint8_t* p_is_infinity, size_t n, uint64_t* out_fq12);
+int bls381_pairing_fixed_q_batch(bls381_ctx*, const bls381_g2_prepared* q, const uint64_t* g1,
+                                 const uint8_t* p_is_infinity, size_t n, uint64_t* out_fq12);
+int bls381_pairing_fixed_q_batch_dev(bls381_ctx*, const bls381_g2_prepared* q, const uint64_t* g1,
+                                     const uint8_t* p_is_infinity, size_t n, uint64_t* out_fq12);
+
 /* Per-step-kind shader-clock accounting of program `which` ("miller", "fe2", ...) run over n
  * groups of zero inputs: out[k] cycles and out[16 + k] step counts of the grid's first wave, k = 0
  * product, 1 sum, 2 sum + carry sweep, 3 two-product, 4.. copies by kind (in, fill, constant, spill,

@@ -49,6 +49,7 @@ static void fill_vm_constants(std::vector<uint32_t>& c) {
 static Dag build_named(const std::string& which) {
     if (which == "miller") return build_miller();
     if (which == "g2prep") return build_g2_prepare();
+    if (which == "millerfq") return build_miller_fixed_q();
     if (which == "ell") return build_ell();
     if (which == "fe1") return build_final_exp_part1();
     if (which == "fe2") return build_final_exp_part2(true);
@@ -61,7 +62,7 @@ static Dag build_named(const std::string& which) {
     if (which == "frob2") return build_frobenius(2);
     throw std::runtime_error("unknown program " + which);
 }
-static const char* ALL_PROGRAMS[] = {"miller", "g2prep", "ell",  "fe1",     "fe2",   "easy2",
+static const char* ALL_PROGRAMS[] = {"miller", "millerfq", "g2prep", "ell",  "fe1",     "fe2",   "easy2",
                                      "hardgen", "inv1",   "inv2", "fq12mul", "frob1", "frob2"};
 
 static bool valid_k(int K) { return K == 6 || K == 8 || K == 9 || K == 12 || K == 16; }
@@ -114,6 +115,7 @@ struct bls381_ctx {
     uint4* d_consts = nullptr;
     uint4* d_vmconsts = nullptr;
     unsigned long long* d_prof = nullptr;  // set while bls381_debug_profile runs
+    const uint4* consts_override = nullptr;  // set while a program runs against a prepared G2 point's table
     DevBuf user_in, user_in2, user_in3, user_out, flags, bufA, bufB, bufC, bufTmp, zflags;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float last_ms[4] = {0, 0, 0, 0};  // Miller kernel, fe1 + inversion, fe2 kernel, whole device call
@@ -255,7 +257,7 @@ static hipError_t launch_vm_kt(bls381_ctx* c, const DevProgram& p, const uint4* 
     constexpr int GPW = 4 * (64 / K);
     VmArgs a;
     a.blocks = p.d_blocks; a.nblocks = p.nblocks; a.nsteps = (int)p.host.hdrs.size(); a.lds_slots = p.host.n_lds_slots;
-    a.prof = c->d_prof; a.consts = c->d_vmconsts; a.gin = gin; a.gout = gout; a.gtmp = gtmp; a.n = n; a.npad = npad;
+    a.prof = c->d_prof; a.consts = c->consts_override ? c->consts_override : c->d_vmconsts; a.gin = gin; a.gout = gout; a.gtmp = gtmp; a.n = n; a.npad = npad;
     // the spill array's 8-byte tails follow its 48-byte parts
     a.gtmp_tail = reinterpret_cast<uint2*>(gtmp + (size_t)std::max(1, p.host.n_tmp_slots) * 3 * npad);
     size_t lds = vm_lds_bytes(p.host.n_lds_slots, K);
@@ -273,7 +275,7 @@ template <int K>
 static hipError_t launch_vm_k(bls381_ctx* c, const DevProgram& p, const uint4* gin, uint4* gout, uint4* gtmp, int n,
                               int npad) {
     if (c->d_prof) return launch_vm_kt<K, TAG_PROFILE>(c, p, gin, gout, gtmp, n, npad);
-    if (p.host.name == "miller") return launch_vm_kt<K, TAG_MILLER>(c, p, gin, gout, gtmp, n, npad);
+    if (p.host.name == "miller" || p.host.name == "millerfq") return launch_vm_kt<K, TAG_MILLER>(c, p, gin, gout, gtmp, n, npad);
     if (p.host.name == "fe2") return launch_vm_kt<K, TAG_FINAL_EXP>(c, p, gin, gout, gtmp, n, npad);
     return launch_vm_kt<K, TAG_AUX>(c, p, gin, gout, gtmp, n, npad);
 }
@@ -392,7 +394,131 @@ extern "C" int bls381_miller_loop_batch_dev(bls381_ctx* c, const uint64_t* g1, c
 // generic "n x in_fp Fp in -> program -> n x out_fp Fp out" on device pointers (up to 3 input arrays)
 struct InArr { const void* p; int fp; };
 static int simple_dev_locked(bls381_ctx* c, const char* prog, std::vector<InArr> ins, size_t n, void* out, int out_fp,
-                             size_t chunk = CHUNK) {
+                             size_t chunk);
+
+// ------------------------------------------------------------------ prepared G2 point (fixed Q, many P)
+struct bls381_g2_prepared {
+    uint4* d_consts = nullptr;  // the interpreter's constants followed by the 408 line-coefficient values
+    bool infinity = false;
+    int device = 0;
+};
+enum { N_COEFF_FP = 68 * 6 };
+
+// Line coefficients in boundary form (slot array, element 0) -> interpreter constants: x R -> x R 2^8
+// (the interpreter's Montgomery factor is 2^392) by eight modular doublings, then 14 digits of 28 bits.
+__global__ void coeffs_to_vm_consts(const uint4* soa, int npad, uint4* consts) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N_COEFF_FP) return;
+    const uint4* p = soa + ((size_t)i * 3) * npad;
+    u32 x[12];
+    unpack3(p[0], p[npad], p[2 * (size_t)npad], x);
+    for (int k = 0; k < 8; k++) {  // x < p < 2^381: 2x fits 12 limbs
+        u32 carry = 0;
+        for (int j = 0; j < 12; j++) { u32 t = (x[j] << 1) | carry; carry = x[j] >> 31; x[j] = t; }
+        fp_cond_sub_p(x);
+    }
+    u32 d[D28];
+    unpack28(x, d);
+    uint4* o = consts + (size_t)(C_COUNT + i) * 4;
+    o[0] = make_uint4(d[0], d[1], d[2], d[3]);
+    o[1] = make_uint4(d[4], d[5], d[6], d[7]);
+    o[2] = make_uint4(d[8], d[9], d[10], d[11]);
+    o[3] = make_uint4(d[12], d[13], 0, 0);
+}
+
+extern "C" int bls381_g2_prepared_create(bls381_ctx* c, const uint64_t* g2, int q_is_infinity, bls381_g2_prepared** out) {
+    CTX_GUARD(c);
+    if (!out) return fail(BLS381_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!q_is_infinity && !g2) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    bls381_g2_prepared* h = new bls381_g2_prepared();
+    h->infinity = q_is_infinity != 0;
+    h->device = c->device;
+    if (!h->infinity) {
+        const size_t rows = (size_t)C_COUNT + N_COEFF_FP;
+        int rc = 0;
+        if (hipMalloc((void**)&h->d_consts, rows * 64) != hipSuccess) rc = fail(BLS381_ERR_HIP, "hipMalloc failed");
+        if (!rc && hipMemcpyAsync(h->d_consts, c->d_vmconsts, (size_t)C_COUNT * 64, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+            rc = fail(BLS381_ERR_HIP, "constant copy failed");
+        // the 68 coefficients of this Q through the same program bls381_g2_prepare_batch runs
+        const int npad = pad_elems(1);
+        if (!rc && (c->user_in.ensure(192) != hipSuccess || c->bufA.ensure(soa_bytes(4, npad)) != hipSuccess ||
+                    c->bufB.ensure(soa_bytes(N_COEFF_FP, npad)) != hipSuccess))
+            rc = fail(BLS381_ERR_HIP, "buffer allocation failed");
+        if (!rc && hipMemcpyAsync(c->user_in.p, g2, 192, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+            rc = fail(BLS381_ERR_HIP, "copy failed");
+        if (!rc) rc = pack(c, c->user_in.p, c->bufA.p, 1, npad, 4, 0);
+        if (!rc) rc = run_program(c, "g2prep", c->bufA.p, c->bufB.p, 1, npad);
+        if (!rc) {
+            hipLaunchKernelGGL(coeffs_to_vm_consts, dim3((N_COEFF_FP + 63) / 64), dim3(64), 0, c->stream,
+                               (const uint4*)c->bufB.p, npad, h->d_consts);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+                rc = fail(BLS381_ERR_HIP, "coefficient conversion failed");
+        }
+        if (rc) { if (h->d_consts) (void)hipFree(h->d_consts); delete h; return rc; }
+    }
+    *out = h;
+    return 0;
+}
+extern "C" void bls381_g2_prepared_destroy(bls381_g2_prepared* h) {
+    if (!h) return;
+    if (h->d_consts) { (void)hipSetDevice(h->device); (void)hipFree(h->d_consts); }
+    delete h;
+}
+
+// n Miller loops (and optionally final exponentiations) of (P_i, Q) for one prepared Q; device pointers
+static int fixed_q_dev_locked(bls381_ctx* c, const bls381_g2_prepared* q, const uint64_t* g1, const uint8_t* flags, size_t n,
+                              uint64_t* out, bool with_final_exp) {
+    for (size_t off = 0; off < n; off += CHUNK) {
+        int m = (int)std::min<size_t>(CHUNK, n - off);
+        int npad = pad_elems(m);
+        HIPCHK(c->bufA.ensure(soa_bytes(2, npad)));
+        HIPCHK(c->bufB.ensure(soa_bytes(12, npad)));
+        HIPCHK(hipEventRecord(c->ev[0], c->stream));
+        int rc = pack(c, g1 + off * 12, c->bufA.p, m, npad, 2, 0);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(c->ev[1], c->stream));
+        if (q->infinity) {  // every pair is skipped: the Miller value is one
+            HIPCHK(c->flags.ensure(m));
+            HIPCHK(hipMemsetAsync(c->flags.p, 1, m, c->stream));
+            hipLaunchKernelGGL(set_one_where_flag, dim3((m + 255) / 256), dim3(256), 0, c->stream, (uint4*)c->bufB.p,
+                               (const uint8_t*)c->flags.p, c->d_consts, m, npad);
+            HIPCHK(hipGetLastError());
+        } else {
+            c->consts_override = q->d_consts;
+            rc = run_program(c, "millerfq", c->bufA.p, c->bufB.p, m, npad);
+            c->consts_override = nullptr;
+            if (rc) return rc;
+            if (flags) {
+                hipLaunchKernelGGL(set_one_where_flag, dim3((m + 255) / 256), dim3(256), 0, c->stream, (uint4*)c->bufB.p,
+                                   flags + off, c->d_consts, m, npad);
+                HIPCHK(hipGetLastError());
+            }
+        }
+        HIPCHK(hipEventRecord(c->ev[2], c->stream));
+        if (with_final_exp) {
+            rc = final_exp_soa(c, c->bufB.p, c->bufB.p, m, npad, nullptr);
+            if (rc) return rc;
+        } else {
+            HIPCHK(hipEventRecord(c->ev[3], c->stream));
+        }
+        HIPCHK(hipEventRecord(c->ev[4], c->stream));
+        rc = unpack(c, c->bufB.p, out + off * 72, m, npad, 12, 0);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(c->ev[5], c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n) {
+        (void)hipEventElapsedTime(&c->last_ms[0], c->ev[1], c->ev[2]);
+        (void)hipEventElapsedTime(&c->last_ms[1], c->ev[2], c->ev[3]);
+        (void)hipEventElapsedTime(&c->last_ms[2], c->ev[3], c->ev[4]);
+        (void)hipEventElapsedTime(&c->last_ms[3], c->ev[0], c->ev[5]);
+    }
+    return 0;
+}
+
+static int simple_dev_locked(bls381_ctx* c, const char* prog, std::vector<InArr> ins, size_t n, void* out, int out_fp,
+                             size_t chunk) {
     int in_fp = 0;
     for (auto& a : ins) in_fp += a.fp;
     for (size_t off = 0; off < n; off += chunk) {
@@ -474,6 +600,44 @@ static int pairs_host(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, con
     if (rc) return rc;
     HIPCHK(hipMemcpy(out, c->user_out.p, n * 576, hipMemcpyDeviceToHost));
     return 0;
+}
+
+static int fixed_q_host(bls381_ctx* c, const bls381_g2_prepared* q, const uint64_t* g1, const uint8_t* flags, size_t n,
+                        uint64_t* out, bool fe) {
+    if (!q) return fail(BLS381_ERR_INVALID, "prepared point is NULL");
+    if (q->device != c->device) return fail(BLS381_ERR_INVALID, "prepared point belongs to another device");
+    if (n && (!g1 || !out)) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    if (n == 0) return 0;
+    int rc;
+    if ((rc = h2d(c, c->user_in, g1, n * 96))) return rc;
+    const uint8_t* fdev = nullptr;
+    if (flags) {
+        if ((rc = h2d(c, c->flags, flags, n))) return rc;
+        fdev = (const uint8_t*)c->flags.p;
+    }
+    HIPCHK(c->user_out.ensure(n * 576));
+    rc = fixed_q_dev_locked(c, q, (const uint64_t*)c->user_in.p, fdev, n, (uint64_t*)c->user_out.p, fe);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out, c->user_out.p, n * 576, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int bls381_miller_loop_fixed_q_batch(bls381_ctx* c, const bls381_g2_prepared* q, const uint64_t* g1,
+                                                const uint8_t* p_is_infinity, size_t n, uint64_t* out) {
+    CTX_GUARD(c);
+    return fixed_q_host(c, q, g1, p_is_infinity, n, out, false);
+}
+extern "C" int bls381_pairing_fixed_q_batch(bls381_ctx* c, const bls381_g2_prepared* q, const uint64_t* g1,
+                                            const uint8_t* p_is_infinity, size_t n, uint64_t* out) {
+    CTX_GUARD(c);
+    return fixed_q_host(c, q, g1, p_is_infinity, n, out, true);
+}
+extern "C" int bls381_pairing_fixed_q_batch_dev(bls381_ctx* c, const bls381_g2_prepared* q, const uint64_t* g1,
+                                                const uint8_t* p_is_infinity, size_t n, uint64_t* out) {
+    CTX_GUARD(c);
+    if (!q) return fail(BLS381_ERR_INVALID, "prepared point is NULL");
+    if (q->device != c->device) return fail(BLS381_ERR_INVALID, "prepared point belongs to another device");
+    if (n && (!g1 || !out)) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    return fixed_q_dev_locked(c, q, g1, p_is_infinity, n, out, true);
 }
 
 extern "C" int bls381_miller_loop_batch(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags,

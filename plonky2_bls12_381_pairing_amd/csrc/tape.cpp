@@ -135,12 +135,15 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
     Program P;
     P.name = name; P.K = K; P.n_in = dag.n_in; P.n_out = dag.n_out;
 
+    // Inputs and constants are never scheduled: they count as values that exist from the start
+    // outside the LDS and are filled in (by a carried copy) right before each use.
+    auto is_load = [&](int i) { return N[i].kind == NK_LOADIN || N[i].kind == NK_LOADC; };
     std::vector<std::vector<int>> succ(n);
     std::vector<int> npred(n, 0);
     for (int i = 0; i < n; i++) {
         std::set<int> srcs;
         for_each_src(N[i], [&](int s) { srcs.insert(s); });
-        for (int s : srcs) { succ[s].push_back(i); npred[i]++; }
+        for (int s : srcs) { succ[s].push_back(i); if (!is_load(s)) npred[i]++; }
     }
     // priority = longest weighted path to a sink
     std::vector<int> prio(n, 0);
@@ -244,9 +247,12 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
     const bool split_mul = env_int2("BLS381_SPLIT_MUL", 0) != 0;
     std::vector<char> done(n, 0);
     std::vector<int> ready;  // nodes whose predecessors all sit in closed steps
-    for (int i = 0; i < n; i++) if (npred[i] == 0) ready.push_back(i);
-    std::vector<RawStep> raw;
     int lo = 0, n_done = 0;
+    for (int i = 0; i < n; i++) {
+        if (is_load(i)) { done[i] = 1; n_done++; }
+        else if (npred[i] == 0) ready.push_back(i);
+    }
+    std::vector<RawStep> raw;
     while (n_done < n) {
         while (lo < n && done[lo]) lo++;
         std::vector<int> cand[4];
@@ -440,7 +446,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
             else { assert(tmp_of[x] >= 0); f = CopyOp{CK_FILL, sl, tmp_of[x]}; }
             // (a step's fills are loaded before its spills are stored: it must not fill what it spills)
             const bool aliases = f.kind == CK_FILL && prev_spilled.count(f.src);
-            if (carrier_prev && how != 2 && prev_nfill < K && f.src < 128 && !aliases) {
+            if (carrier_prev && how != 2 && prev_nfill < K && f.src < 1024 && !aliases) {
                 OpDesc& d = P.descs[prev_idx * K + prev_nfill++];
                 d.w[9] = (uint16_t)(sl | 0x8000); d.w[10] = (uint16_t)(f.src | ((uint32_t)f.kind << 12));
                 P.hdrs[prev_idx].max_terms |= 1u << 16;

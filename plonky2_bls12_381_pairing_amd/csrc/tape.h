@@ -73,6 +73,9 @@ Dag build_miller();
 // G2Prepared::from: the 68 line coefficients.                /root/reference/src/native/miller_loop.rs:90-119
 // gin: G2 (4); gout: 68 * 6 (coefficient k, Fq2 j, component c at 6*k + 2*j + c).
 Dag build_g2_prepare();
+// The Miller loop with the 68 line coefficients taken from constants C_COUNT .. C_COUNT + 408
+// (a prepared G2 point shared by the whole batch).  gin: G1 (2); gout: Fq12 (12).
+Dag build_miller_fixed_q();
 // ell(f, coeffs, p).                                         /root/reference/src/native/miller_loop.rs:185-194
 // gin: f (12) + coeff (6) + G1 (2); gout: f (12).
 Dag build_ell();

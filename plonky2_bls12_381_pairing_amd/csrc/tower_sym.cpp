@@ -366,6 +366,32 @@ Dag build_miller() {
     return d;
 }
 
+// Miller loop against line coefficients prepared once (G2Prepared::ell_coeffs reused for many P,
+// /root/reference/src/native/miller_loop.rs:13-16, 139-156): the 68 coefficients are constants
+// C_COUNT + 6 k + {c0.c0, c0.c1, c1.c0, c1.c1, c2.c0, c2.c1}, only f is computed.  gin: G1 (2).
+Dag build_miller_fixed_q() {
+    Dag d;
+    d.n_in = 2; d.n_out = 12;
+    Tower T(d);
+    SFq12 f = T.one12();
+    const SFp px = T.in(0), py = T.in(1);
+    int k = 0;
+    auto coeff = [&]() {
+        const int b = C_COUNT + 6 * k++;
+        return Tower::EllCoeff{{T.cst(b), T.cst(b + 1)}, {T.cst(b + 2), T.cst(b + 3)}, {T.cst(b + 4), T.cst(b + 5)}};
+    };
+    for (int i = 62; i >= 0; i--) {
+        f = T.sqr(f);
+        f = T.ell(f, coeff(), px, py);
+        if ((BLS381_X >> i) & 1) f = T.ell(f, coeff(), px, py);
+    }
+    assert(k == 68);
+    f = T.conj(f);
+    T.out12(f, 0);
+    d.optimise();
+    return d;
+}
+
 Dag build_g2_prepare() {
     Dag d;
     d.n_in = 4; d.n_out = 68 * 6;

@@ -76,8 +76,8 @@ enum { LIN_MAX_TERMS = 7, MAX_LDS_SLOTS = 128 };
 //        carries a fill, bit 24 some lane carries a spill)
 //   w[1], w[2]  multiplier and sum steps: operand i in byte i, LDS slot in bits 0..6, negate in bit 7;
 //               copy steps: w[1] = source slot
-//   w[3]        carried copies: bits 0..6 fill LDS slot, 7..8 CopyKind, 9..15 source slot, 16 valid;
-//               bits 17..23 spill LDS slot, 24..30 spill-array slot, 31 valid
+//   w[3]        carried copies: bits 0..6 fill LDS slot, 7..8 CopyKind, 9..18 source slot, 19 valid;
+//               bits 20..26 spill LDS slot, 27 valid; the spill-array slot sits in w[0] bits 25..31
 struct PackedDesc {
     uint32_t w[4];
 };
@@ -96,8 +96,11 @@ inline PackedDesc pack_desc(const StepHdr& h, const OpDesc& d) {
             p.w[1 + i / 4] |= b << (8 * (i % 4));
         }
         if (d.w[9] & 0x8000u)
-            p.w[3] |= (d.w[9] & 0x7fu) | (((d.w[10] >> 12) & 3u) << 7) | ((d.w[10] & 0x7fu) << 9) | (1u << 16);
-        if (d.w[11] & 0x8000u) p.w[3] |= ((d.w[11] & 0x7fu) << 17) | ((d.w[12] & 0x7fu) << 24) | (1u << 31);
+            p.w[3] |= (d.w[9] & 0x7fu) | (((d.w[10] >> 12) & 3u) << 7) | ((d.w[10] & 0x3ffu) << 9) | (1u << 19);
+        if (d.w[11] & 0x8000u) {
+            p.w[3] |= ((d.w[11] & 0x7fu) << 20) | (1u << 27);
+            p.w[0] |= (d.w[12] & 0x7fu) << 25;
+        }
     }
     return p;
 }  // seven 2^28-bounded digits and their carries fit 32 bits

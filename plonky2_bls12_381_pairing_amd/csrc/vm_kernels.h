@@ -149,8 +149,8 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
         if (carries && (hx & (1u << 23))) {
             // a fill may read what a spill of an earlier step wrote: drain the wave's stores first
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane_on && (dw & (1u << 16))) {
-                const u32 fk = (dw >> 7) & 3u, src = (dw >> 9) & 0x7fu;
+            if (lane_on && (dw & (1u << 19))) {
+                const u32 fk = (dw >> 7) & 3u, src = (dw >> 9) & 0x3ffu;
                 if (fk == CK_CONST) {
                     const uint4* p = A.consts + (size_t)src * 4;
                     uint4 v0 = p[0], v1 = p[1], v2 = p[2];
@@ -174,10 +174,10 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
         }
 
         if (carries && (hx & (1u << 24))) {
-            if (lane_on && (dw >> 31)) {
+            if (lane_on && (dw & (1u << 27))) {
                 u32 v[D28];
-                lds_load((dw >> 17) & 0x7fu, v);
-                const u32 t = (dw >> 24) & 0x7fu;
+                lds_load((dw >> 20) & 0x7fu, v);
+                const u32 t = dx >> 25;
                 uint4* p = A.gtmp + ((size_t)t * 3) * A.npad + e;
                 p[0] = make_uint4(v[0], v[1], v[2], v[3]);
                 p[A.npad] = make_uint4(v[4], v[5], v[6], v[7]);
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             // every path consumes the loaded registers here (see the copy step)
             asm volatile("" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]), "+v"(pf[6]),
                               "+v"(pf[7]), "+v"(pf[8]), "+v"(pf[9]), "+v"(pf[10]), "+v"(pf[11]), "+v"(pf[12]), "+v"(pf[13]));
-            if (lane_on && (dw & (1u << 16))) {
+            if (lane_on && (dw & (1u << 19))) {
                 if (((dw >> 7) & 3u) == CK_IN) {
                     u32 l[12];
 #pragma unroll

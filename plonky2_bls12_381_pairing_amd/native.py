@@ -41,6 +41,30 @@ def _flags(f, n):
     return f
 
 
+class G2Prepared:
+    """Device-resident G2Prepared (68 line coefficients of one G2 point, miller_loop.rs:13-16)."""
+
+    def __init__(self, ctx, g2, infinity=False):
+        self._p = C.c_void_p()
+        g2 = _arr64(np.asarray(g2 if g2 is not None else np.zeros(24), dtype=np.uint64).reshape(1, 24), 24)
+        check(lib.bls381_g2_prepared_create(ctx._h, _p64(g2), int(bool(infinity)), C.byref(self._p)))
+
+    @property
+    def handle(self):
+        return self._p
+
+    def close(self):
+        if self._p:
+            lib.bls381_g2_prepared_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """One GPU.  lanes_per_group / lds_slots = 0 select the defaults."""
 
@@ -75,6 +99,29 @@ class Context:
         fl = _flags(inf_flags, n)
         out = np.empty((n, 72), dtype=np.uint64)
         check(lib.bls381_miller_loop_batch(self._h, _p64(g1), _p64(g2), _p8(fl), n, _p64(out)))
+        return out
+
+    # ---- G2Prepared reused for many P (miller_loop.rs:13-16, 139-156)
+    def g2_prepared(self, g2, infinity=False):
+        """G2Prepared::from(q) kept on the device: returns a G2Prepared handle object."""
+        return G2Prepared(self, g2, infinity)
+
+    def miller_loop_fixed_q_batch(self, prepared, g1, p_is_infinity=None):
+        """multi_miller_loop_native([p_i], [q]) for every p_i against one prepared q."""
+        g1 = _arr64(g1, 12)
+        n = g1.shape[0]
+        fl = _flags(p_is_infinity, n)
+        out = np.empty((n, 72), dtype=np.uint64)
+        check(lib.bls381_miller_loop_fixed_q_batch(self._h, prepared.handle, _p64(g1), _p8(fl), n, _p64(out)))
+        return out
+
+    def pairing_fixed_q_batch(self, prepared, g1, p_is_infinity=None):
+        """native_pairing([p_i], [q]) for every p_i against one prepared q."""
+        g1 = _arr64(g1, 12)
+        n = g1.shape[0]
+        fl = _flags(p_is_infinity, n)
+        out = np.empty((n, 72), dtype=np.uint64)
+        check(lib.bls381_pairing_fixed_q_batch(self._h, prepared.handle, _p64(g1), _p8(fl), n, _p64(out)))
         return out
 
     def multi_miller_loop_native(self, g1, g2, inf_flags=None):

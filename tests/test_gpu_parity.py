@@ -312,3 +312,31 @@ def test_fp_inverse_kernel_against_big_integers(ctx):
     want = np.array([R.fq_to_u32_limbs(pow(x, -1, R.P) * r2 % R.P if x else 0) for x in vals], dtype=np.uint32)
     assert np.array_equal(out, want)
     assert flags.tolist() == [int(x == 0) for x in vals]
+
+
+def test_fixed_q_mode_against_general_path_and_oracle(ctx):
+    """One prepared G2 point against many G1 points (G2Prepared reuse, miller_loop.rs:13-16): Miller
+    values and pairings equal the general entry points on (P_i, Q) bit for bit, equal the Python oracle
+    on a sample, honour the infinity flags, and a prepared point at infinity yields one everywhere."""
+    n = 300
+    ps, qs = H.random_pairs(n, 2024)
+    q = qs[0]
+    g1 = H.g1_array(ps)
+    g2 = np.repeat(H.g2_array([q]), n, axis=0)
+    flags = np.zeros(n, dtype=np.uint8)
+    flags[[3, 77, 299]] = 1
+    prep = ctx.g2_prepared(H.g2_array([q])[0])
+    ml = ctx.miller_loop_fixed_q_batch(prep, g1, flags)
+    assert np.array_equal(ml, ctx.miller_loop_batch(g1, g2, flags))
+    pr = ctx.pairing_fixed_q_batch(prep, g1, flags)
+    assert np.array_equal(pr, ctx.pairing_batch(g1, g2, flags))
+    for i in (0, 1, 150):
+        assert H.fq12_from_row(ml[i]) == R.multi_miller_loop([ps[i]], [q])
+        assert H.fq12_from_row(pr[i]) == R.native_pairing([ps[i]], [q])
+    one = H.fq12_array([R.FQ12_ONE])[0]
+    assert np.array_equal(pr[3], one) and np.array_equal(ml[77], one)
+    prep.close()
+    inf = ctx.g2_prepared(None, infinity=True)
+    assert all(np.array_equal(r, one) for r in ctx.pairing_fixed_q_batch(inf, g1[:5]))
+    inf.close()
+    assert ctx.pairing_fixed_q_batch(ctx.g2_prepared(H.g2_array([q])[0]), g1[:0]).shape == (0, 72)

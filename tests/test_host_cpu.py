@@ -107,6 +107,22 @@ def test_auxiliary_programs():
     assert S.run_program(S.get_program("inv2"), mid) == R.myfq12_from_fq12(R.fq12_inv(a))
 
 
+def test_fixed_q_miller_program():
+    """The Miller program that takes its 68 line coefficients from the constant table (one prepared Q,
+    many P) against multi_miller_loop_native on the same pair."""
+    ps, qs = H.random_pairs(1, 4711)
+    p, q = ps[0], qs[0]
+    coeffs = [x for cf in R.g2_prepare(q) for fq2 in cf for x in fq2]
+    assert len(coeffs) == 408
+    extra = [x * (1 << 392) % R.P for x in coeffs]
+    prog = S.get_program("millerfq")
+    assert prog["n_in"] == 2 and prog["n_out"] == 12
+    out = S.run_program(prog, [M(p[0]), M(p[1])], extra_consts=extra)
+    assert R.fq12_from_flat_ark([F(x) for x in out]) == R.multi_miller_loop([p], [q])
+    # the prepared form drops the G2 arithmetic: about 5,192 of the 7,141 multiplications remain
+    assert prog["n_fmul"] < 0.8 * S.get_program("miller")["n_fmul"]
+
+
 def test_program_statistics():
     """Multiplier work, counted in the work model's unit (12-limb multiply-accumulates: 300 per product,
     444 per two-product sum with its single reduction), stays within 2% of the reference work model

@@ -139,10 +139,11 @@ def canon(d):
     return v + P if v < 0 else (v - P if v >= P else v)
 
 
-def run_program(prog, gin, strict=True):
-    """gin: list of ints in boundary form (12 x u32 patterns), one per input slot.  Returns gout list."""
+def run_program(prog, gin, strict=True, extra_consts=()):
+    """gin: list of ints in boundary form (12 x u32 patterns), one per input slot; extra_consts: values
+    (times 2^392 mod p) that follow the built-in constant table.  Returns gout list."""
     K = prog["K"]
-    consts = [to_digits(c) for c in get_constants()]
+    consts = [to_digits(c) for c in list(get_constants()) + list(extra_consts)]
     lds = [None] * prog["lds_slots"]
     lds[prog["lds_slots"] - 2] = [0] * 14      # the ZERO slot; the last slot is TRASH
     gtmp = {}
@@ -162,7 +163,7 @@ def run_program(prog, gin, strict=True):
                 if w9 & 0x8000:
                     any_fill = True
                     kind, src = w10 >> 12, w10 & 0xfff
-                    assert src < 128
+                    assert src < 1024
                     if kind == CK_IN:
                         val = to_digits(gin[src])
                     elif kind == CK_FILL:
