@@ -135,6 +135,21 @@ int bls381_debug_fp_mul(bls381_ctx*, const uint32_t* a, const uint32_t* b, size_
 int bls381_debug_fp_inverse(bls381_ctx*, const uint32_t* a, size_t n, uint32_t* out, uint8_t* is_zero);
 /* The interpreter's constant table: C_COUNT rows of 16 u32 (14 digits of 28 bits, zero padded). */
 int bls381_debug_constants(uint32_t* out, size_t capacity_fp);
+/* ---- the other witness generators of the reference --------------------------------------------
+ * Canonical (non-Montgomery) 12 x u32 limbs in and out, as the generators read them with
+ * get_biguint_target and write them with set_biguint_target.  err (optional) gets one byte per
+ * element; a non-zero byte marks an element on which the reference panics (or limbs >= p), its
+ * output is zero and the call returns BLS381_ERR_ZERO after filling all outputs.
+ *   FqSqrtGenerator   /root/reference/src/fields/fq_target.rs:296-323   x, sgn -> the root whose parity bit is sgn
+ *   Fq2SqrtGenerator  /root/reference/src/fields/fq2_target.rs:401-428  x (c0, c1), sgn -> the root with sgn0_fq2 = sgn
+ *   Fq2InverseGenerator  fq2_target.rs:347-369   x -> 1/x, zero -> zero (no error)
+ *   Fq6InverseGenerator  /root/reference/src/fields/fq6_target.rs:350-371   x in MyFq6 order
+ *                        [c0.c0, c1.c0, c2.c0, c0.c1, c1.c1, c2.c1] -> 1/x in the same order; zero is an error */
+int bls381_fq_sqrt_limbs_batch(bls381_ctx*, const uint32_t* x, const uint8_t* sgn, size_t n, uint32_t* out, uint8_t* err);
+int bls381_fq2_sqrt_limbs_batch(bls381_ctx*, const uint32_t* x, const uint8_t* sgn, size_t n, uint32_t* out, uint8_t* err);
+int bls381_fq2_inverse_limbs_batch(bls381_ctx*, const uint32_t* x, size_t n, uint32_t* out, uint8_t* err);
+int bls381_fq6_inverse_limbs_batch(bls381_ctx*, const uint32_t* x, size_t n, uint32_t* out, uint8_t* err);
+
 /* ---- one G2 point against many G1 points ------------------------------------------------------
  * G2Prepared (/root/reference/src/native/miller_loop.rs:13-16, 90-119) holds the 68 line coefficients
  * of Q so that they are computed once and reused by every Miller loop against that Q (:139-156).

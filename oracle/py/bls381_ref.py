@@ -384,3 +384,80 @@ def fq_to_u64_limbs(a): return [(a >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in ra
 def fq_to_u32_limbs(a): return [(a >> (32 * i)) & 0xFFFFFFFF for i in range(12)]
 def u32_limbs_to_int(l): return sum(int(x) << (32 * i) for i, x in enumerate(l))
 def u64_limbs_to_int(l): return sum(int(x) << (64 * i) for i, x in enumerate(l))
+
+
+# ---------------------------------------------------------------- the other witness generators
+# Values the in-repo generators of the reference put into the witness; each output is determined by
+# its inputs alone (the square roots through the requested sign), so they are pinned by mathematics:
+# out^2 = x, sgn0(out) = sgn, out * x = 1.
+def sgn0_fq(x):
+    """/root/reference/src/utils/helpers.rs:159-167: parity of the canonical integer."""
+    return (x % P) & 1 == 1
+
+def sgn0_fq2(x):
+    """/root/reference/src/utils/helpers.rs:169-174."""
+    return sgn0_fq(x[0]) or (x[0] % P == 0 and sgn0_fq(x[1]))
+
+def fq_sqrt(x):
+    """A square root of x in Fq (p = 3 mod 4), or None."""
+    r = pow(x % P, (P + 1) // 4, P)
+    return r if r * r % P == x % P else None
+
+def fq2_sqrt(a):
+    """A square root of a in Fq2 = Fq[u]/(u^2+1), or None."""
+    a0, a1 = a[0] % P, a[1] % P
+    if a1 == 0:
+        s = fq_sqrt(a0)
+        if s is not None:
+            return (s, 0)
+        return (0, fq_sqrt((-a0) % P))          # -1 is a non-residue: -a0 is a square
+    g = fq_sqrt((a0 * a0 + a1 * a1) % P)
+    if g is None:
+        return None
+    half = (P + 1) // 2
+    x0 = fq_sqrt((a0 + g) * half % P)
+    if x0 is None:
+        x0 = fq_sqrt((a0 - g) * half % P)
+    x1 = a1 * fq_inv(2 * x0 % P) % P
+    r = (x0, x1)
+    assert fq2_square(r) == (a0, a1)
+    return r
+
+def fq_sqrt_generator(x, sgn):
+    """FqSqrtGenerator::run_once, /root/reference/src/fields/fq_target.rs:296-323: the square root
+    whose parity bit equals sgn.  Raises where the reference panics (no root, or root 0 with sgn set)."""
+    r = fq_sqrt(x)
+    if r is None:
+        raise ValueError("sqrt of a non-residue")
+    if sgn0_fq(r) != bool(sgn):
+        r = (-r) % P
+    if sgn0_fq(r) != bool(sgn):
+        raise ValueError("requested sign cannot be met")
+    return r
+
+def fq2_sqrt_generator(x, sgn):
+    """Fq2SqrtGenerator::run_once, /root/reference/src/fields/fq2_target.rs:401-428."""
+    r = fq2_sqrt(x)
+    if r is None:
+        raise ValueError("sqrt of a non-square")
+    if sgn0_fq2(r) != bool(sgn):
+        r = fq2_neg(r)
+    if sgn0_fq2(r) != bool(sgn):
+        raise ValueError("requested sign cannot be met")
+    return r
+
+def fq2_inverse_generator(x):
+    """Fq2InverseGenerator::run_once, /root/reference/src/fields/fq2_target.rs:347-369: zero maps to zero."""
+    if x[0] % P == 0 and x[1] % P == 0:
+        return (0, 0)
+    return fq2_inv(x)
+
+def fq6_inverse_generator(coeffs):
+    """Fq6InverseGenerator::run_once, /root/reference/src/fields/fq6_target.rs:350-371, on MyFq6 order
+    [c0.c0, c1.c0, c2.c0, c0.c1, c1.c1, c2.c1] (/root/reference/src/utils/my_fq6.rs:12-44).  Raises on zero."""
+    c = [v % P for v in coeffs]
+    a = ((c[0], c[3]), (c[1], c[4]), (c[2], c[5]))
+    if all(v == 0 for v in c):
+        raise ZeroDivisionError("inverse of zero in Fq6")
+    r = fq6_inv(a)
+    return [r[0][0], r[1][0], r[2][0], r[0][1], r[1][1], r[2][1]]

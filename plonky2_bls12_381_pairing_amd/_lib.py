@@ -56,6 +56,10 @@ _sig("bls381_g2_prepared_destroy", None, C.c_void_p)
 _sig("bls381_miller_loop_fixed_q_batch", C.c_int, ctxp, C.c_void_p, u64p, C.POINTER(C.c_uint8), C.c_size_t, u64p)
 _sig("bls381_pairing_fixed_q_batch", C.c_int, ctxp, C.c_void_p, u64p, C.POINTER(C.c_uint8), C.c_size_t, u64p)
 _sig("bls381_pairing_fixed_q_batch_dev", C.c_int, ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+_sig("bls381_fq_sqrt_limbs_batch", C.c_int, ctxp, u32p, C.POINTER(C.c_uint8), C.c_size_t, u32p, C.POINTER(C.c_uint8))
+_sig("bls381_fq2_sqrt_limbs_batch", C.c_int, ctxp, u32p, C.POINTER(C.c_uint8), C.c_size_t, u32p, C.POINTER(C.c_uint8))
+_sig("bls381_fq2_inverse_limbs_batch", C.c_int, ctxp, u32p, C.c_size_t, u32p, C.POINTER(C.c_uint8))
+_sig("bls381_fq6_inverse_limbs_batch", C.c_int, ctxp, u32p, C.c_size_t, u32p, C.POINTER(C.c_uint8))
 _sig("bls381_debug_program", C.c_int, C.c_char_p, C.c_int, C.c_int, u32p, u32p, C.c_size_t, u32p)
 _sig("bls381_debug_constants", C.c_int, u32p, C.c_size_t)
 _sig("bls381_debug_profile", C.c_int, C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64))
@@ -73,6 +77,7 @@ EXPORTED = [
     "bls381_fq12_inverse_limbs_batch", "bls381_pairing_witness_rows", "bls381_pairing_witness_kinds",
     "bls381_pairing_witness_batch", "bls381_pairing_batch_dev", "bls381_miller_loop_batch_dev",
     "bls381_final_exp_batch_dev", "bls381_g2_prepared_create", "bls381_g2_prepared_destroy",
+    "bls381_fq_sqrt_limbs_batch", "bls381_fq2_sqrt_limbs_batch", "bls381_fq2_inverse_limbs_batch", "bls381_fq6_inverse_limbs_batch",
     "bls381_miller_loop_fixed_q_batch", "bls381_pairing_fixed_q_batch", "bls381_pairing_fixed_q_batch_dev", "bls381_debug_program", "bls381_debug_constants", "bls381_debug_profile", "bls381_debug_fp_mul", "bls381_debug_fp_inverse", "bls381_last_timing",
     "bls381_calibrate_mac_rate",
 ]

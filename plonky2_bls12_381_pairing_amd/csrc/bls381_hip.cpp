@@ -14,6 +14,7 @@
 #include "bls381_constants.h"
 #include "tape.h"
 #include "vm_kernels.h"
+#include "generators.h"
 #include "witness.h"
 
 using namespace bls381;
@@ -999,6 +1000,63 @@ extern "C" int bls381_debug_fp_inverse(bls381_ctx* c, const uint32_t* a, size_t 
     HIPCHK(hipMemcpy(out, c->user_out.p, n * 48, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(is_zero, c->zflags.p, n, hipMemcpyDeviceToHost));
     return 0;
+}
+
+// ------------------------------------------------------------------ the other witness generators
+// n x in_fq canonical Fq in -> kernel -> n x out_fq canonical Fq out + one error byte per element
+template <typename Launch>
+static int generator_host(bls381_ctx* c, const uint32_t* x, const uint8_t* sgn, size_t n, int in_fq, int out_fq,
+                          uint32_t* out, uint8_t* err, const char* what, Launch launch) {
+    if (n == 0) return 0;
+    if (!x || !out) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    if (n > (size_t)1 << 24) return fail(BLS381_ERR_INVALID, "at most 2^24 elements per call");
+    int rc;
+    if ((rc = h2d(c, c->user_in, x, n * in_fq * 48))) return rc;
+    if (sgn && (rc = h2d(c, c->flags, sgn, n))) return rc;
+    HIPCHK(c->user_out.ensure(n * out_fq * 48));
+    HIPCHK(c->zflags.ensure(n));
+    launch((const u32*)c->user_in.p, (const uint8_t*)c->flags.p, (int)n, (u32*)c->user_out.p, (uint8_t*)c->zflags.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->user_out.p, n * out_fq * 48, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> e(n);
+    HIPCHK(hipMemcpy(e.data(), c->zflags.p, n, hipMemcpyDeviceToHost));
+    if (err) std::memcpy(err, e.data(), n);
+    for (size_t i = 0; i < n; i++)
+        if (e[i]) return fail(BLS381_ERR_ZERO, std::string(what) + " (item " + std::to_string(i) + ")");
+    return 0;
+}
+extern "C" int bls381_fq_sqrt_limbs_batch(bls381_ctx* c, const uint32_t* x, const uint8_t* sgn, size_t n, uint32_t* out,
+                                          uint8_t* err) {
+    CTX_GUARD(c);
+    if (n && !sgn) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    return generator_host(c, x, sgn, n, 1, 1, out, err, "no square root with the requested sign",
+                          [&](const u32* xd, const uint8_t* sd, int m, u32* od, uint8_t* ed) {
+                              hipLaunchKernelGGL(gen::fq_sqrt_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, xd, sd, m, od, ed);
+                          });
+}
+extern "C" int bls381_fq2_sqrt_limbs_batch(bls381_ctx* c, const uint32_t* x, const uint8_t* sgn, size_t n, uint32_t* out,
+                                           uint8_t* err) {
+    CTX_GUARD(c);
+    if (n && !sgn) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    return generator_host(c, x, sgn, n, 2, 2, out, err, "no square root with the requested sign",
+                          [&](const u32* xd, const uint8_t* sd, int m, u32* od, uint8_t* ed) {
+                              hipLaunchKernelGGL(gen::fq2_sqrt_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, xd, sd, m, od, ed);
+                          });
+}
+extern "C" int bls381_fq2_inverse_limbs_batch(bls381_ctx* c, const uint32_t* x, size_t n, uint32_t* out, uint8_t* err) {
+    CTX_GUARD(c);
+    return generator_host(c, x, nullptr, n, 2, 2, out, err, "limbs do not encode a field element",
+                          [&](const u32* xd, const uint8_t*, int m, u32* od, uint8_t* ed) {
+                              hipLaunchKernelGGL(gen::fq2_inverse_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, xd, m, od, ed);
+                          });
+}
+extern "C" int bls381_fq6_inverse_limbs_batch(bls381_ctx* c, const uint32_t* x, size_t n, uint32_t* out, uint8_t* err) {
+    CTX_GUARD(c);
+    return generator_host(c, x, nullptr, n, 6, 6, out, err, "inverse of zero in Fq6",
+                          [&](const u32* xd, const uint8_t*, int m, u32* od, uint8_t* ed) {
+                              hipLaunchKernelGGL(gen::fq6_inverse_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, xd, m, od, ed);
+                          });
 }
 
 // sustained v_mad_u64_u32 rate: 8 independent accumulators per lane, 8 waves per SIMD

@@ -429,23 +429,9 @@ __device__ __forceinline__ void apply(int* a, int* b, int u, int v, int q, int r
 }
 }  // namespace inv30
 
-__global__ __launch_bounds__(64) void fp_inverse_kernel(uint4* soa, int slot, int n, int npad, const uint4* consts,
-                                                        uint8_t* is_zero) {
+// x R -> x^-1 R on 12 x u32 (0 -> 0); the caller tests for zero
+__device__ __noinline__ void fp_invert_boundary(const u32* a, u32* res) {
     using namespace inv30;
-    (void)consts;
-    long el = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (el >= n) return;
-    uint4* p = soa + ((size_t)slot * 3) * npad + el;
-    u32 a[12];
-    {
-        uint4 v0 = p[0], v1 = p[npad], v2 = p[2 * (size_t)npad];
-        unpack3(v0, v1, v2, a);
-    }
-    u32 nz = 0;
-#pragma unroll
-    for (int i = 0; i < 12; i++) nz |= a[i];
-    if (is_zero) is_zero[el] = (nz == 0);
-
     int f[NL] = BLS381_P30_LIMBS, g[NL], d[NL], e[NL];
 #pragma unroll
     for (int i = 0; i < NL; i++) {
@@ -504,7 +490,7 @@ __global__ __launch_bounds__(64) void fp_inverse_kernel(uint4* soa, int slot, in
 #pragma unroll
     for (int i = 0; i < NL - 1; i++) { d[i + 1] += d[i] >> 30; d[i] &= BLS381_M30; }
     // 13 x 30 bits -> 12 x 32, then (x R)^-1 * R^3 / R = x^-1 R
-    u32 x[12], res[12];
+    u32 x[12];
 #pragma unroll
     for (int w = 0; w < 12; w++) {
         const int bit = 32 * w, i = bit / 30, s = bit - 30 * i;
@@ -516,6 +502,24 @@ __global__ __launch_bounds__(64) void fp_inverse_kernel(uint4* soa, int slot, in
     const u32 R3[12] = {0xd94ca1e0u, 0xed48ac6bu, 0x03a7adf8u, 0x315f831eu, 0x615e29ddu, 0x9a53352au,
                         0x921e1761u, 0x34c04e5eu, 0x65724728u, 0x2512d435u, 0x91755d4du, 0x0aa63460u};  // R^3 mod p
     fp_mul(x, R3, res);
+}
+
+__global__ __launch_bounds__(64) void fp_inverse_kernel(uint4* soa, int slot, int n, int npad, const uint4* consts,
+                                                        uint8_t* is_zero) {
+    (void)consts;
+    long el = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (el >= n) return;
+    uint4* p = soa + ((size_t)slot * 3) * npad + el;
+    u32 a[12], res[12];
+    {
+        uint4 v0 = p[0], v1 = p[npad], v2 = p[2 * (size_t)npad];
+        unpack3(v0, v1, v2, a);
+    }
+    u32 nz = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) nz |= a[i];
+    if (is_zero) is_zero[el] = (nz == 0);
+    fp_invert_boundary(a, res);
     p[0] = make_uint4(res[0], res[1], res[2], res[3]);
     p[npad] = make_uint4(res[4], res[5], res[6], res[7]);
     p[2 * (size_t)npad] = make_uint4(res[8], res[9], res[10], res[11]);

@@ -231,6 +231,53 @@ class Context:
         check(lib.bls381_fq12_inverse_limbs_batch(self._h, _p32(x), n, _p32(inv), _p8(err)))
         return inv
 
+    # ---- the other witness generators (canonical 12 x u32 limbs in and out)
+    def _limbs_call(self, fn, x, cols, sgn=None):
+        x = np.ascontiguousarray(x, dtype=np.uint32)
+        if x.ndim != 2 or x.shape[1] != cols:
+            raise ValueError("expected shape (n, %d)" % cols)
+        n = x.shape[0]
+        out = np.empty((n, cols), dtype=np.uint32)
+        err = np.zeros(n, dtype=np.uint8)
+        if sgn is None:
+            rc = fn(self._h, _p32(x), n, _p32(out), _p8(err))
+        else:
+            sgn = np.ascontiguousarray(sgn, dtype=np.uint8)
+            if sgn.shape != (n,):
+                raise ValueError("sgn must have shape (n,)")
+            rc = fn(self._h, _p32(x), _p8(sgn), n, _p32(out), _p8(err))
+        return rc, out, err
+
+    def fq_sqrt_limbs_batch(self, x, sgn, return_err=False):
+        """FqSqrtGenerator::run_once (fields/fq_target.rs:296-323) per element."""
+        rc, out, err = self._limbs_call(lib.bls381_fq_sqrt_limbs_batch, x, 12, sgn)
+        if return_err:
+            return out, err
+        check(rc)
+        return out
+
+    def fq2_sqrt_limbs_batch(self, x, sgn, return_err=False):
+        """Fq2SqrtGenerator::run_once (fields/fq2_target.rs:401-428) per element."""
+        rc, out, err = self._limbs_call(lib.bls381_fq2_sqrt_limbs_batch, x, 24, sgn)
+        if return_err:
+            return out, err
+        check(rc)
+        return out
+
+    def fq2_inverse_limbs_batch(self, x):
+        """Fq2InverseGenerator::run_once (fields/fq2_target.rs:347-369) per element."""
+        rc, out, err = self._limbs_call(lib.bls381_fq2_inverse_limbs_batch, x, 24)
+        check(rc)
+        return out
+
+    def fq6_inverse_limbs_batch(self, x, return_err=False):
+        """Fq6InverseGenerator::run_once (fields/fq6_target.rs:350-371) per element, MyFq6 order."""
+        rc, out, err = self._limbs_call(lib.bls381_fq6_inverse_limbs_batch, x, 72)
+        if return_err:
+            return out, err
+        check(rc)
+        return out
+
     def pairing_witness_batch(self, g1, g2):
         g1, g2 = _arr64(g1, 12), _arr64(g2, 24)
         n = g1.shape[0]

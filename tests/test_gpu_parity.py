@@ -340,3 +340,56 @@ def test_fixed_q_mode_against_general_path_and_oracle(ctx):
     assert all(np.array_equal(r, one) for r in ctx.pairing_fixed_q_batch(inf, g1[:5]))
     inf.close()
     assert ctx.pairing_fixed_q_batch(ctx.g2_prepared(H.g2_array([q])[0]), g1[:0]).shape == (0, 72)
+
+
+def test_other_witness_generators(ctx):
+    """FqSqrt / Fq2Sqrt / Fq2Inverse / Fq6Inverse generator values on canonical limbs against the Python
+    oracle: random inputs, both requested signs, the edge cases (0, 1, p-1, pure-real and pure-imaginary
+    Fq2 squares), and the inputs on which the reference panics (non-residues, zero in Fq6, limbs >= p)."""
+    import random
+    import plonky2_bls12_381_pairing_amd as B
+    rng = random.Random(55)
+    L = lambda v: R.fq_to_u32_limbs(v)
+    # Fq square roots
+    xs = [0, 1, 4, R.P - 1, 2] + [rng.randrange(R.P) ** 2 % R.P for _ in range(150)] + [rng.randrange(R.P) for _ in range(150)]
+    sg = [0, 1, 0, 1, 1] + [rng.randrange(2) for _ in range(300)]
+    out, err = ctx.fq_sqrt_limbs_batch(np.array([L(x) for x in xs], dtype=np.uint32), sg, return_err=True)
+    n_err = 0
+    for x, s, o, e in zip(xs, sg, out, err):
+        try:
+            want = R.fq_sqrt_generator(x, s)
+            assert e == 0 and R.u32_limbs_to_int(o) == want
+        except ValueError:
+            assert e == 1 and not o.any()
+            n_err += 1
+    assert 50 < n_err < 250
+    # Fq2 square roots
+    pts = [(0, 0), (1, 0), (R.P - 1, 0), (0, 1), (0, R.P - 4), (9, 0)]
+    pts += [R.fq2_square((rng.randrange(R.P), rng.randrange(R.P))) for _ in range(150)]
+    pts += [(rng.randrange(R.P), rng.randrange(R.P)) for _ in range(100)]
+    sg = [rng.randrange(2) for _ in pts]
+    sg[0] = 0
+    out, err = ctx.fq2_sqrt_limbs_batch(np.array([L(a) + L(b) for a, b in pts], dtype=np.uint32), sg, return_err=True)
+    for a, s, o, e in zip(pts, sg, out, err):
+        try:
+            want = R.fq2_sqrt_generator(a, s)
+            assert e == 0 and (R.u32_limbs_to_int(o[:12]), R.u32_limbs_to_int(o[12:])) == want, (a, s)
+        except ValueError:
+            assert e == 1 and not o.any()
+    assert 20 < int(err.sum()) < 90
+    # Fq2 inverses: zero maps to zero without an error
+    pts = [(0, 0), (1, 0), (0, 1), (R.P - 1, R.P - 1)] + [(rng.randrange(R.P), rng.randrange(R.P)) for _ in range(200)]
+    out = ctx.fq2_inverse_limbs_batch(np.array([L(a) + L(b) for a, b in pts], dtype=np.uint32))
+    for a, o in zip(pts, out):
+        assert (R.u32_limbs_to_int(o[:12]), R.u32_limbs_to_int(o[12:])) == R.fq2_inverse_generator(a)
+    # Fq6 inverses in MyFq6 order; zero and out-of-range limbs are errors
+    cs = [[1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], [0, 1, 0, 0, 0, 0]] + [[rng.randrange(R.P) for _ in range(6)] for _ in range(100)]
+    out = ctx.fq6_inverse_limbs_batch(np.array([sum((L(v) for v in c), []) for c in cs], dtype=np.uint32))
+    for c, o in zip(cs, out):
+        assert [R.u32_limbs_to_int(o[12 * k:12 * k + 12]) for k in range(6)] == R.fq6_inverse_generator(c)
+    bad = np.array([sum((L(v) for v in c), []) for c in ([0] * 6, cs[5])], dtype=np.uint32)
+    bad[1, :12] = L(R.P)
+    with pytest.raises(B.Bls381Error):
+        ctx.fq6_inverse_limbs_batch(bad)
+    out, err = ctx.fq6_inverse_limbs_batch(bad, return_err=True)
+    assert err.tolist() == [1, 1] and not out.any()

@@ -153,3 +153,26 @@ def test_divstep_inversion_model():
     xs = [0, 1, 2, D.P - 1, D.P - 2, (D.P + 1) // 2, 1 << 380] + [rng.randrange(D.P) for _ in range(300)]
     for x in xs:
         assert D.modinv(x) == (pow(x, -1, D.P) if x else 0)
+
+
+def test_other_generator_oracles():
+    """Square-root and inverse generator restatements satisfy their defining equations."""
+    rng = random.Random(21)
+    for _ in range(40):
+        x, s = rng.randrange(R.P), rng.randrange(2)
+        try:
+            r = R.fq_sqrt_generator(x, s)
+            assert r * r % R.P == x and (r & 1) == s
+        except ValueError:
+            assert pow(x, (R.P - 1) // 2, R.P) == R.P - 1 or x == 0
+        a = (rng.randrange(R.P), rng.randrange(R.P))
+        sq = R.fq2_square(a)
+        r = R.fq2_sqrt_generator(sq, s)
+        assert R.fq2_square(r) == sq and R.sgn0_fq2(r) == bool(s)
+        assert R.fq2_mul(R.fq2_inverse_generator(a), a) == (1, 0)
+        c = [rng.randrange(R.P) for _ in range(6)]
+        inv = R.fq6_inverse_generator(c)
+        A = ((c[0], c[3]), (c[1], c[4]), (c[2], c[5]))
+        Bv = ((inv[0], inv[3]), (inv[1], inv[4]), (inv[2], inv[5]))
+        assert R.fq6_mul(A, Bv) == R.FQ6_ONE
+    assert R.fq2_inverse_generator((0, 0)) == (0, 0)
