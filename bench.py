@@ -168,6 +168,18 @@ def main():
             t1 = time.perf_counter()
             CO.pairing_batch(g1[idx], g2[idx])
             dt = time.perf_counter() - t1
+            # second row: the same work with an optimised final exponentiation (cyclotomic squarings), so that
+            # the reference's slow MyFq12 products do not inflate the ratio
+            CO.set_fast(True)
+            t2 = time.perf_counter()
+            CO.pairing_batch(g1[idx], g2[idx])
+            dt_fast = time.perf_counter() - t2
+            CO.set_fast(False)
+            res["cpu_baseline_optimised"] = {
+                "value": nsamp / dt_fast, "unit": "pairings/s", "cores": cores, "kind": "port",
+                "sample": "the same %d pairings with Granger-Scott cyclotomic squarings and Karatsuba tower products "
+                          "in the final exponentiation (same values, not the reference's algorithm), %.1f s" % (nsamp, dt_fast),
+            }
             res["cpu_baseline"] = {
                 "value": nsamp / dt, "unit": "pairings/s", "cores": cores, "kind": "port",
                 "sample": "%d pairings of the same batch (C restatement of the reference's native algorithm incl. its "

@@ -323,7 +323,42 @@ static int easy_part(myfp12* r, const myfp12* a) { /* final_exponentiation.rs:8-
     my_mul(r, &f3, &f2);
     return 0;
 }
-static void pow_x_fp12(fp12* r, const fp12* a) { myfp12 m, o; my_from_fp12(&m, a); my_pow_x(&o, &m); my_to_fp12(r, &o); }
+/* Optimised variant (not the reference's algorithm, same values): Karatsuba tower products and
+ * Granger-Scott squarings in the cyclotomic subgroup instead of the 144-multiplication MyFq12 product.
+ * Switched by orc_set_fast; reported as a second CPU row so that the reference's slow final
+ * exponentiation does not inflate the GPU speed-up. */
+static int g_fast = 0;
+void orc_set_fast(int on) { g_fast = on; }
+static void fp4_sqr(fp2* even, fp2* odd, const fp2* x, const fp2* y) { /* (x + y s)^2, s^2 = xi */
+    fp2 xy, t, u, v;
+    fp2_mul(&xy, x, y);
+    fp2_add(&t, x, y); fp2_mul_xi(&u, y); fp2_add(&u, &u, x); fp2_mul(&t, &t, &u);
+    fp2_mul_xi(&v, &xy);
+    fp2_sub(&t, &t, &xy); fp2_sub(even, &t, &v);
+    fp2_dbl(odd, &xy);
+}
+static void fp12_cyclotomic_sqr(fp12* r, const fp12* a) {
+    const fp2 r0 = a->c0.c0, r4 = a->c0.c1, r3 = a->c0.c2, r2 = a->c1.c0, r1 = a->c1.c1, r5 = a->c1.c2;
+    fp2 t0, t1, t2, t3, t4, t5, z, x5;
+    fp4_sqr(&t0, &t1, &r0, &r1); fp4_sqr(&t2, &t3, &r2, &r3); fp4_sqr(&t4, &t5, &r4, &r5);
+#define Z3M2(dst, t, rr) do { fp2_sub(&z, &(t), &(rr)); fp2_dbl(&z, &z); fp2_add(&(dst), &z, &(t)); } while (0)  /* 3t - 2r */
+#define Z3P2(dst, t, rr) do { fp2_add(&z, &(t), &(rr)); fp2_dbl(&z, &z); fp2_add(&(dst), &z, &(t)); } while (0)  /* 3t + 2r */
+    Z3M2(r->c0.c0, t0, r0); Z3P2(r->c1.c1, t1, r1);
+    fp2_mul_xi(&x5, &t5);
+    Z3P2(r->c1.c0, x5, r2); Z3M2(r->c0.c2, t4, r3);
+    Z3M2(r->c0.c1, t2, r4); Z3P2(r->c1.c2, t3, r5);
+#undef Z3M2
+#undef Z3P2
+}
+static void pow_x_fp12(fp12* r, const fp12* a) {
+    if (g_fast) {  /* valid for the cyclotomic-subgroup elements the hard part raises */
+        fp12 res = *a;
+        for (int i = 62; i >= 0; i--) { fp12_cyclotomic_sqr(&res, &res); if ((BLS_X >> i) & 1) fp12_mul(&res, &res, a); }
+        *r = res;
+        return;
+    }
+    myfp12 m, o; my_from_fp12(&m, a); my_pow_x(&o, &m); my_to_fp12(r, &o);
+}
 static void frob_fp12(fp12* r, const fp12* a, int p) { myfp12 m, o; my_from_fp12(&m, a); my_frobenius(&o, &m, p); my_to_fp12(r, &o); }
 static void hard_part(fp12* out, const fp12* rin) { /* :44-72 */
     fp12 r = *rin, y0, y1, y2;

@@ -98,5 +98,12 @@ lib.orc_set_threads.argtypes = [C.c_int]
 lib.orc_get_max_threads.restype = C.c_int
 
 
+def set_fast(on):
+    """Optimised CPU variant (cyclotomic squarings, Karatsuba tower products) instead of the reference's algorithm."""
+    lib.orc_set_fast.restype = None
+    lib.orc_set_fast.argtypes = [C.c_int]
+    lib.orc_set_fast(int(bool(on)))
+
+
 def set_threads(n):
     lib.orc_set_threads(int(n))

@@ -176,3 +176,18 @@ def test_other_generator_oracles():
         Bv = ((inv[0], inv[3]), (inv[1], inv[4]), (inv[2], inv[5]))
         assert R.fq6_mul(A, Bv) == R.FQ6_ONE
     assert R.fq2_inverse_generator((0, 0)) == (0, 0)
+
+
+def test_c_oracle_optimised_variant_gives_the_same_values():
+    """The second CPU row of the benchmark (cyclotomic squarings instead of the reference's 144-multiplication
+    products) computes bit-identical pairings."""
+    import c_oracle as CO
+    ps, qs = H.random_pairs(6, 909)
+    g1, g2 = H.g1_array(ps), H.g2_array(qs)
+    ref = CO.pairing_batch(g1, g2)
+    CO.set_fast(True)
+    try:
+        fast = CO.pairing_batch(g1, g2)
+    finally:
+        CO.set_fast(False)
+    assert np.array_equal(ref, fast)
