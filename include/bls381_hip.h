@@ -105,6 +105,10 @@ int bls381_fq12_inverse_limbs_batch(bls381_ctx*, const uint32_t* x, size_t n, ui
 size_t bls381_pairing_witness_rows(void);
 int bls381_pairing_witness_kinds(uint8_t* kinds, size_t capacity);
 int bls381_pairing_witness_batch(bls381_ctx*, const uint64_t* g1, const uint64_t* g2, size_t n_proofs, uint32_t* trace);
+/* The same with g1, g2 and trace in device memory: the trace is written in place (6.79 MB per proof;
+ * the copy to the host is what dominates the host-pointer form). */
+int bls381_pairing_witness_batch_dev(bls381_ctx*, const uint64_t* g1, const uint64_t* g2, size_t n_proofs,
+                                     uint32_t* trace);
 
 /* Device-resident variants: all pointers are device memory on the context's GPU; they run on the
  * context's stream and return after the work has completed. */

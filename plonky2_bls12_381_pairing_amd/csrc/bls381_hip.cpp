@@ -907,6 +907,20 @@ extern "C" int bls381_pairing_witness_batch(bls381_ctx* c, const uint64_t* g1, c
     return 0;
 }
 
+extern "C" int bls381_pairing_witness_batch_dev(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t n,
+                                                uint32_t* trace) {
+    CTX_GUARD(c);
+    if (n == 0) return 0;
+    if (!g1 || !g2 || !trace) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    std::string err;
+    auto inv = [](void* cx, const uint32_t* x_dev, size_t m, uint32_t* inv_dev) -> int {
+        return inverse_limbs_dev_locked((bls381_ctx*)cx, x_dev, m, inv_dev, nullptr);
+    };
+    int rc = c->wit.run(c->stream, c, inv, g1, g2, n, trace, err, /*on_device=*/true);
+    if (rc) return fail(rc, err.empty() ? g_err : err);
+    return 0;
+}
+
 // ------------------------------------------------------------------ introspection
 extern "C" int bls381_debug_program(const char* which, int K, int lds_slots, uint32_t* hdrs, uint32_t* descs,
                                     size_t capacity_steps, uint32_t info[8]) {

@@ -484,7 +484,7 @@ static hipError_t ensure(void*& p, size_t& have, size_t need) {
 }
 
 int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint64_t* g1, const uint64_t* g2, size_t n,
-                       uint32_t* trace, std::string& err) {
+                       uint32_t* trace, std::string& err, bool on_device) {
     const WitnessProgram& P = witness_program();
     if (!uploaded_) {
         for (int ph = 0; ph < 2; ph++) {
@@ -501,37 +501,39 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         WCHK(hipMemcpy(d_inv_refs_, P.inv_input_refs, 48, hipMemcpyHostToDevice));
         uploaded_ = true;
     }
-    const size_t CH = 64;  // proofs per pass: 64 x 6.8 MB of trace
+    const size_t CH = 512;  // proofs per pass (one workgroup each: two per CU): 512 x 6.8 MB of trace
     for (size_t off = 0; off < n; off += CH) {
         int m = (int)std::min(CH, n - off);
         size_t tbytes = (size_t)m * P.n_rows * 48;
-        WCHK(ensure(d_trace_, trace_bytes_, tbytes));
+        if (!on_device) WCHK(ensure(d_trace_, trace_bytes_, tbytes));
+        u32* const d_trace_m = on_device ? trace + off * P.n_rows * 12 : (u32*)d_trace_;
         WCHK(ensure(d_inputs_, inputs_bytes_, (size_t)m * 6 * 48));
         WCHK(ensure(d_x_, x_bytes_, (size_t)m * 576 * 2));
         WCHK(ensure(d_g_, g_bytes_, (size_t)m * 288));
         u32* d_g1 = (u32*)d_g_;
         u32* d_g2 = d_g1 + (size_t)m * 24;
-        WCHK(hipMemcpyAsync(d_g1, g1 + off * 12, (size_t)m * 96, hipMemcpyHostToDevice, stream));
-        WCHK(hipMemcpyAsync(d_g2, g2 + off * 24, (size_t)m * 192, hipMemcpyHostToDevice, stream));
+        const hipMemcpyKind in_kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        WCHK(hipMemcpyAsync(d_g1, g1 + off * 12, (size_t)m * 96, in_kind, stream));
+        WCHK(hipMemcpyAsync(d_g2, g2 + off * 24, (size_t)m * 192, in_kind, stream));
         hipLaunchKernelGGL(witness_inputs_kernel, dim3((m * 6 + 63) / 64), dim3(64), 0, stream, d_g1, d_g2, (u32*)d_inputs_, m);
         WCHK(hipGetLastError());
         hipLaunchKernelGGL(witness_kernel, dim3(m), dim3(256), 0, stream, d_ops_[0], d_levels_[0],
-                           (int)P.level_start[0].size() - 1, (u32*)d_trace_, P.n_rows, d_consts_, (const u32*)d_inputs_);
+                           (int)P.level_start[0].size() - 1, d_trace_m, P.n_rows, d_consts_, (const u32*)d_inputs_);
         WCHK(hipGetLastError());
         u32* d_x = (u32*)d_x_;
         u32* d_inv = d_x + (size_t)m * 144;
-        hipLaunchKernelGGL(witness_gather_kernel, dim3((m * 12 + 63) / 64), dim3(64), 0, stream, (const u32*)d_trace_,
+        hipLaunchKernelGGL(witness_gather_kernel, dim3((m * 12 + 63) / 64), dim3(64), 0, stream, (const u32*)d_trace_m,
                            P.n_rows, d_inv_refs_, d_x, m);
         WCHK(hipGetLastError());
         int rc = inv(ctx, d_x, (size_t)m, d_inv);
         if (rc) { err = "Fq12 inversion inside the witness trace failed (zero Miller value?)"; return rc; }
-        hipLaunchKernelGGL(witness_scatter_kernel, dim3((m * 12 + 63) / 64), dim3(64), 0, stream, (u32*)d_trace_, P.n_rows,
+        hipLaunchKernelGGL(witness_scatter_kernel, dim3((m * 12 + 63) / 64), dim3(64), 0, stream, d_trace_m, P.n_rows,
                            P.gen_start, d_inv, m);
         WCHK(hipGetLastError());
         hipLaunchKernelGGL(witness_kernel, dim3(m), dim3(256), 0, stream, d_ops_[1], d_levels_[1],
-                           (int)P.level_start[1].size() - 1, (u32*)d_trace_, P.n_rows, d_consts_, (const u32*)d_inputs_);
+                           (int)P.level_start[1].size() - 1, d_trace_m, P.n_rows, d_consts_, (const u32*)d_inputs_);
         WCHK(hipGetLastError());
-        WCHK(hipMemcpyAsync(trace + off * P.n_rows * 12, d_trace_, tbytes, hipMemcpyDeviceToHost, stream));
+        if (!on_device) WCHK(hipMemcpyAsync(trace + off * P.n_rows * 12, d_trace_, tbytes, hipMemcpyDeviceToHost, stream));
         WCHK(hipStreamSynchronize(stream));
     }
     return 0;

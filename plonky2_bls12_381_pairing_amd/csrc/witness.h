@@ -57,8 +57,9 @@ class WitnessDevice {
     // `run_inverse` performs the Fq12 inversion of n values given as device canonical limbs (n x 144 u32, MyFq12
     // order) into device canonical limbs; it is supplied by the context (lane-group programs inv1/inv2).
     typedef int (*inverse_fn)(void* ctx, const uint32_t* x_dev, size_t n, uint32_t* inv_dev);
+    // on_device: g1, g2 and trace are device pointers; the trace is then written in place, no staging copy
     int run(hipStream_t stream, void* ctx, inverse_fn inv, const uint64_t* g1, const uint64_t* g2, size_t n,
-            uint32_t* trace, std::string& err);
+            uint32_t* trace, std::string& err, bool on_device = false);
     void release();
 
    private:

@@ -393,3 +393,20 @@ def test_other_witness_generators(ctx):
         ctx.fq6_inverse_limbs_batch(bad)
     out, err = ctx.fq6_inverse_limbs_batch(bad, return_err=True)
     assert err.tolist() == [1, 1] and not out.any()
+
+
+def test_witness_trace_device_pointer_form(ctx):
+    """bls381_pairing_witness_batch_dev writes the trace in place in device memory: same bytes as the
+    host-pointer form."""
+    import torch
+    from plonky2_bls12_381_pairing_amd import _lib
+    ps, qs = H.random_pairs(3, 606)
+    g1, g2 = H.g1_array(ps), H.g2_array(qs)
+    want = ctx.pairing_witness_batch(g1, g2)
+    dev = torch.device("cuda", 0)
+    d1 = torch.from_numpy(g1.view(np.int64)).to(dev)
+    d2 = torch.from_numpy(g2.view(np.int64)).to(dev)
+    out = torch.zeros(want.size, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib.bls381_pairing_witness_batch_dev(ctx.handle, d1.data_ptr(), d2.data_ptr(), 3, out.data_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(want.shape), want)
