@@ -410,3 +410,19 @@ def test_witness_trace_device_pointer_form(ctx):
     _lib.check(_lib.lib.bls381_pairing_witness_batch_dev(ctx.handle, d1.data_ptr(), d2.data_ptr(), 3, out.data_ptr()))
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(want.shape), want)
+
+
+@pytest.mark.parametrize("lanes,slots", [(6, 0), (9, 0), (12, 0), (16, 0), (8, 36)])
+def test_other_lane_group_geometries(lanes, slots):
+    """Every compiled lane-group width (and a reduced LDS slot count, which forces more spilling) computes
+    the same pairings and fixed-Q pairings as the oracle."""
+    import plonky2_bls12_381_pairing_amd as B
+    ps, qs = H.random_pairs(11, 1000 + lanes)
+    g1, g2 = H.g1_array(ps), H.g2_array(qs)
+    with B.Context(0, lanes, slots) as c:
+        out = c.pairing_batch(g1, g2)
+        for i in (0, 5, 10):
+            assert H.fq12_from_row(out[i]) == R.native_pairing([ps[i]], [qs[i]])
+        prep = c.g2_prepared(g2[2])
+        assert np.array_equal(c.pairing_fixed_q_batch(prep, g1[2:3]), out[2:3])
+        prep.close()
