@@ -106,7 +106,8 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
     u32 nz = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)cur.z);
     for (int b = 0; b < A.nblocks; b++) {
       const uint4 ahead = bptr[(size_t)min(b + 2, last_block) * 64];
-      for (int j = 0; j < SPB && s < A.nsteps; j++, s++) {
+      const int nj = min((int)SPB, A.nsteps - s);  // steps of this block
+      for (int j = 0; j < nj; j++, s++) {
         const u32 dx = nx, dy = ny, dz = nz;
         if (j + 1 < SPB) {  // a branch, not a select: the next block's registers are touched once per block only
             const int from = ((j + 1) * K + role) * 4;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
         u32 pf[D28];  // deliberately not initialised: a merge with constants would make the compiler copy
                       // the loaded registers, and so wait for the loads, right where they are issued
         u32 dw = 0;   // the descriptor word of the carried copies, fetched only by steps that carry any
-        const bool carries = type != ST_COPY && (hx & (3u << 23));
+        const bool carries = type != ST_COPY && (hx & (3u << 23));  // (a copy step's destination field extends over these bits)
         if (carries) {
             dw = (u32)__builtin_amdgcn_ds_bpermute((j * K + role) * 4, (int)cur.w);
             asm volatile("" : "+v"(dw));  // nothing derived from dw is computed (and waited for) by steps that carry nothing
@@ -186,28 +187,7 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             }
         }
         // Multiplier and sum steps are branch-free: idle lanes read the ZERO slot and store to TRASH.
-        if (type == ST_FMUL) {
-            u32 a[D28], b[D28], r[D28];
-            lds_load(OP(0), a);
-            lds_load(OP(1), b);
-            fp28_mul(a, b, r);
-            lds_store(dst, r);
-        } else if (type == ST_DOT2) {
-            u32 a[D28], b[D28], c[D28], d[D28], r[D28];
-            lds_load(OP(0), a);
-            lds_load(OP(1), b);
-            lds_load(OP(2), c);
-            lds_load(OP(3), d);
-            {
-                // a*b - c*d: negate d digit by digit, -d = (d ^ -1) + 1
-                const u32 m = (dx & 4u) ? 0xffffffffu : 0u;
-                const u32 one = m & 1u;
-#pragma unroll
-                for (int i = 0; i < D28; i++) d[i] = (d[i] ^ m) + one;
-            }
-            fp28_dot2(a, b, c, d, r);
-            lds_store(dst, r);
-        } else if (type == ST_LIN) {
+        if (type == ST_LIN) {  // most frequent first
             // acc = sum of (x ^ m), m = -1 for negated terms: each of those is one short of -x, which
             // the first term makes up for by starting from the count of negated terms.  The loads
             // of up to four terms are issued together so their latencies overlap.
@@ -242,6 +222,27 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             if (flags & 2u) reduce28(acc);  // sweeps as well
             else if (flags) normalise28(acc);
             lds_store(dst, acc);
+        } else if (type == ST_DOT2) {
+            u32 a[D28], b[D28], c[D28], d[D28], r[D28];
+            lds_load(OP(0), a);
+            lds_load(OP(1), b);
+            lds_load(OP(2), c);
+            lds_load(OP(3), d);
+            {
+                // a*b - c*d: negate d digit by digit, -d = (d ^ -1) + 1
+                const u32 m = (dx & 4u) ? 0xffffffffu : 0u;
+                const u32 one = m & 1u;
+#pragma unroll
+                for (int i = 0; i < D28; i++) d[i] = (d[i] ^ m) + one;
+            }
+            fp28_dot2(a, b, c, d, r);
+            lds_store(dst, r);
+        } else if (type == ST_FMUL) {
+            u32 a[D28], b[D28], r[D28];
+            lds_load(OP(0), a);
+            lds_load(OP(1), b);
+            fp28_mul(a, b, r);
+            lds_store(dst, r);
         } else {  // ST_COPY: every lane reads before any lane writes
             const u32 kind = (dx >> 10) & 7u;
             const u32 src = dy;
