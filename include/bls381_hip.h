@@ -39,6 +39,16 @@ enum {
     BLS381_ERR_NO_DEVICE = -2, /* no usable gfx950 device / HIP runtime failure at start-up */
     BLS381_ERR_HIP = -3,       /* a HIP call failed; see bls381_last_error() */
     BLS381_ERR_ZERO = -4,      /* an input that the reference rejects by panicking (zero divisor) */
+    BLS381_ERR_POINT = -5,     /* an encoded point was rejected; the per-point status says why */
+};
+
+/* Per-point status of the decoding calls. */
+enum {
+    BLS381_POINT_OK = 0,
+    BLS381_POINT_INFINITY = 1,        /* a valid encoding of the point at infinity */
+    BLS381_POINT_BAD_ENCODING = 2,    /* flag bits inconsistent, uncompressed form, or x >= p */
+    BLS381_POINT_NOT_ON_CURVE = 3,    /* x^3 + b is not a square */
+    BLS381_POINT_NOT_IN_SUBGROUP = 4, /* on the curve but outside the order-r subgroup */
 };
 
 /* Creates a context on HIP device `device_id`.  Builds and uploads the step programs. */
@@ -153,6 +163,33 @@ int bls381_fq_sqrt_limbs_batch(bls381_ctx*, const uint32_t* x, const uint8_t* sg
 int bls381_fq2_sqrt_limbs_batch(bls381_ctx*, const uint32_t* x, const uint8_t* sgn, size_t n, uint32_t* out, uint8_t* err);
 int bls381_fq2_inverse_limbs_batch(bls381_ctx*, const uint32_t* x, size_t n, uint32_t* out, uint8_t* err);
 int bls381_fq6_inverse_limbs_batch(bls381_ctx*, const uint32_t* x, size_t n, uint32_t* out, uint8_t* err);
+
+/* ---- compressed points and aggregation: the step before the path in BLS signature verification --
+ * The reference takes ark-ec points (/root/reference/src/native/pairing.rs:8-13); its callers decode
+ * them with ark-bls12-381 0.4.0 (/root/reference/Cargo.toml:13) G1Affine / G2Affine
+ * deserialize_compressed and encode them with serialize_compressed.  These calls do that for whole
+ * batches: 48 bytes per G1 point (big-endian x), 96 per G2 point (big-endian x.c1 then x.c0), top
+ * bits of byte 0 = 0x80 compressed, 0x40 infinity, 0x20 y is the lexicographically larger root.
+ * Decoded points come out in the G1 / G2 layout above, ready for the pairing calls; status (may be
+ * NULL) gets one BLS381_POINT_* byte per point, rejected points are zero and the call returns
+ * BLS381_ERR_POINT after filling everything.  A point at infinity is status 1 with a zero point:
+ * pass it on through inf_flags.  check_subgroup != 0 also runs the order-r membership test that
+ * deserialize_compressed performs (Validate::Yes); 0 corresponds to deserialize_compressed_unchecked
+ * plus the on-curve test. */
+int bls381_g1_decompress_batch(bls381_ctx*, const uint8_t* in48, size_t n, int check_subgroup, uint64_t* g1,
+                               uint8_t* status);
+int bls381_g2_decompress_batch(bls381_ctx*, const uint8_t* in96, size_t n, int check_subgroup, uint64_t* g2,
+                               uint8_t* status);
+/* inf (may be NULL): one byte per point, non-zero = the point at infinity. */
+int bls381_g1_compress_batch(bls381_ctx*, const uint64_t* g1, const uint8_t* inf, size_t n, uint8_t* out48);
+int bls381_g2_compress_batch(bls381_ctx*, const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* out96);
+/* Sums of n_groups groups of group_size points each (ark-ec `G1Projective::sum` / the `+` of public
+ * keys or signatures before /root/reference/src/native/pairing.rs:8-13 sees them): points laid out
+ * group after group, inf as above; out gets one affine point per group, out_inf its infinity flag. */
+int bls381_g1_aggregate_batch(bls381_ctx*, const uint64_t* g1, const uint8_t* inf, size_t n_groups, size_t group_size,
+                              uint64_t* out, uint8_t* out_inf);
+int bls381_g2_aggregate_batch(bls381_ctx*, const uint64_t* g2, const uint8_t* inf, size_t n_groups, size_t group_size,
+                              uint64_t* out, uint8_t* out_inf);
 
 /* ---- one G2 point against many G1 points ------------------------------------------------------
  * G2Prepared (/root/reference/src/native/miller_loop.rs:13-16, 90-119) holds the 68 line coefficients

@@ -15,6 +15,7 @@
 #include "tape.h"
 #include "vm_kernels.h"
 #include "generators.h"
+#include "points.h"
 #include "witness.h"
 
 using namespace bls381;
@@ -1071,6 +1072,125 @@ extern "C" int bls381_fq6_inverse_limbs_batch(bls381_ctx* c, const uint32_t* x, 
                           [&](const u32* xd, const uint8_t*, int m, u32* od, uint8_t* ed) {
                               hipLaunchKernelGGL(gen::fq6_inverse_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, xd, m, od, ed);
                           });
+}
+
+// ------------------------------------------------------------------ compressed points, aggregation
+static const size_t MAX_POINTS = (size_t)1 << 22;
+// n encodings of `bytes_per` bytes -> n affine points of `fq_out` Fq each + one status byte per point
+template <typename Launch>
+static int decompress_host(bls381_ctx* c, const uint8_t* in, size_t n, size_t bytes_per, size_t fq_out, uint64_t* out,
+                           uint8_t* status, Launch launch) {
+    if (n == 0) return 0;
+    if (!in || !out) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    if (n > MAX_POINTS) return fail(BLS381_ERR_INVALID, "at most 2^22 points per call");
+    int rc;
+    if ((rc = h2d(c, c->user_in, in, n * bytes_per))) return rc;
+    HIPCHK(c->user_out.ensure(n * fq_out * 48));
+    HIPCHK(c->zflags.ensure(n));
+    launch((const uint8_t*)c->user_in.p, (int)n, (u32*)c->user_out.p, (uint8_t*)c->zflags.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->user_out.p, n * fq_out * 48, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> st(n);
+    HIPCHK(hipMemcpy(st.data(), c->zflags.p, n, hipMemcpyDeviceToHost));
+    if (status) std::memcpy(status, st.data(), n);
+    for (size_t i = 0; i < n; i++)
+        if (st[i] >= BLS381_POINT_BAD_ENCODING) {
+            static const char* const why[] = {"", "", "malformed encoding", "x is not on the curve", "not in the order-r subgroup"};
+            return fail(BLS381_ERR_POINT, std::string(why[st[i] <= 4 ? st[i] : 2]) + " (item " + std::to_string(i) + ")");
+        }
+    return 0;
+}
+extern "C" int bls381_g1_decompress_batch(bls381_ctx* c, const uint8_t* in, size_t n, int check_subgroup, uint64_t* g1,
+                                          uint8_t* status) {
+    CTX_GUARD(c);
+    return decompress_host(c, in, n, 48, 2, g1, status, [&](const uint8_t* d, int m, u32* o, uint8_t* s) {
+        hipLaunchKernelGGL(pts::g1_decompress_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, d, m, check_subgroup, o, s);
+    });
+}
+extern "C" int bls381_g2_decompress_batch(bls381_ctx* c, const uint8_t* in, size_t n, int check_subgroup, uint64_t* g2,
+                                          uint8_t* status) {
+    CTX_GUARD(c);
+    return decompress_host(c, in, n, 96, 4, g2, status, [&](const uint8_t* d, int m, u32* o, uint8_t* s) {
+        hipLaunchKernelGGL(pts::g2_decompress_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, d, m, check_subgroup, o, s);
+    });
+}
+template <typename Launch>
+static int compress_host(bls381_ctx* c, const uint64_t* pts_in, const uint8_t* inf, size_t n, size_t fq_in, size_t bytes_per,
+                         uint8_t* out, Launch launch) {
+    if (n == 0) return 0;
+    if (!pts_in || !out) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    if (n > MAX_POINTS) return fail(BLS381_ERR_INVALID, "at most 2^22 points per call");
+    int rc;
+    if ((rc = h2d(c, c->user_in, pts_in, n * fq_in * 48))) return rc;
+    if (inf && (rc = h2d(c, c->flags, inf, n))) return rc;
+    HIPCHK(c->user_out.ensure(n * bytes_per));
+    launch((const u32*)c->user_in.p, inf ? (const uint8_t*)c->flags.p : nullptr, (int)n, (uint8_t*)c->user_out.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->user_out.p, n * bytes_per, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int bls381_g1_compress_batch(bls381_ctx* c, const uint64_t* g1, const uint8_t* inf, size_t n, uint8_t* out) {
+    CTX_GUARD(c);
+    return compress_host(c, g1, inf, n, 2, 48, out, [&](const u32* d, const uint8_t* f, int m, uint8_t* o) {
+        hipLaunchKernelGGL(pts::g1_compress_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, d, f, m, o);
+    });
+}
+extern "C" int bls381_g2_compress_batch(bls381_ctx* c, const uint64_t* g2, const uint8_t* inf, size_t n, uint8_t* out) {
+    CTX_GUARD(c);
+    return compress_host(c, g2, inf, n, 4, 96, out, [&](const u32* d, const uint8_t* f, int m, uint8_t* o) {
+        hipLaunchKernelGGL(pts::g2_compress_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, d, f, m, o);
+    });
+}
+// sums of n_groups groups of group_size points each
+template <class T>
+static int aggregate_host(bls381_ctx* c, const uint64_t* pts_in, const uint8_t* inf, size_t n_groups, size_t group_size,
+                          uint64_t* out, uint8_t* out_inf) {
+    constexpr size_t FQ = pts::Width<T>::FQ;
+    if (n_groups == 0) return 0;
+    if (!pts_in || !out || !out_inf) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    if (group_size == 0) return fail(BLS381_ERR_INVALID, "empty groups");
+    if (group_size > MAX_POINTS || n_groups > MAX_POINTS / group_size)
+        return fail(BLS381_ERR_INVALID, "at most 2^22 points per call");
+    const size_t n = n_groups * group_size;
+    int rc;
+    if ((rc = h2d(c, c->user_in, pts_in, n * 2 * FQ * 48))) return rc;
+    if (inf && (rc = h2d(c, c->flags, inf, n))) return rc;
+    size_t count = group_size, half = (count + 1) / 2;
+    HIPCHK(c->bufA.ensure(n_groups * half * 3 * FQ * 48));
+    HIPCHK(c->bufB.ensure(n_groups * ((half + 1) / 2) * 3 * FQ * 48));
+    u32 *cur = (u32*)c->bufA.p, *other = (u32*)c->bufB.p;
+    auto blocks = [](size_t threads) { return dim3((unsigned)((threads + 63) / 64)); };
+    hipLaunchKernelGGL(pts::agg_first_kernel<T>, blocks(n_groups * half), dim3(64), 0, c->stream, (const u32*)c->user_in.p,
+                       inf ? (const uint8_t*)c->flags.p : nullptr, (int)n_groups, (int)count, (int)half, cur);
+    HIPCHK(hipGetLastError());
+    for (count = half; count > 1; count = half) {
+        half = (count + 1) / 2;
+        hipLaunchKernelGGL(pts::agg_pass_kernel<T>, blocks(n_groups * half), dim3(64), 0, c->stream, (const u32*)cur,
+                           (int)n_groups, (int)count, (int)half, other);
+        HIPCHK(hipGetLastError());
+        std::swap(cur, other);
+    }
+    HIPCHK(c->user_out.ensure(n_groups * 2 * FQ * 48));
+    HIPCHK(c->zflags.ensure(n_groups));
+    hipLaunchKernelGGL(pts::agg_finish_kernel<T>, blocks(n_groups), dim3(64), 0, c->stream, (const u32*)cur, (int)n_groups,
+                       (u32*)c->user_out.p, (uint8_t*)c->zflags.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->user_out.p, n_groups * 2 * FQ * 48, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_inf, c->zflags.p, n_groups, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int bls381_g1_aggregate_batch(bls381_ctx* c, const uint64_t* g1, const uint8_t* inf, size_t n_groups,
+                                         size_t group_size, uint64_t* out, uint8_t* out_inf) {
+    CTX_GUARD(c);
+    return aggregate_host<gen::F>(c, g1, inf, n_groups, group_size, out, out_inf);
+}
+extern "C" int bls381_g2_aggregate_batch(bls381_ctx* c, const uint64_t* g2, const uint8_t* inf, size_t n_groups,
+                                         size_t group_size, uint64_t* out, uint8_t* out_inf) {
+    CTX_GUARD(c);
+    return aggregate_host<gen::F2>(c, g2, inf, n_groups, group_size, out, out_inf);
 }
 
 // sustained v_mad_u64_u32 rate: 8 independent accumulators per lane, 8 waves per SIMD

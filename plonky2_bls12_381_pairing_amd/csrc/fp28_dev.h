@@ -117,8 +117,8 @@ __device__ __forceinline__ void xor_add28(u32* acc, const u32* x, u32 m) {
         "v_xad_u32 %11, %25, %28, %11\n\t"
         "v_xad_u32 %12, %26, %28, %12\n\t"
         "v_xad_u32 %13, %27, %28, %13"
-        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
-          "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13])
+        : "+&v"(acc[0]), "+&v"(acc[1]), "+&v"(acc[2]), "+&v"(acc[3]), "+&v"(acc[4]), "+&v"(acc[5]), "+&v"(acc[6]),
+          "+&v"(acc[7]), "+&v"(acc[8]), "+&v"(acc[9]), "+&v"(acc[10]), "+&v"(acc[11]), "+&v"(acc[12]), "+&v"(acc[13])
         : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]),
           "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]), "v"(x[13]), "v"(m));
 }

@@ -126,13 +126,8 @@ __global__ __launch_bounds__(64) void fq2_inverse_kernel(const u32* x, int n, u3
     err[i] = ok ? 0 : 1;
 }
 
-// Fq2SqrtGenerator::run_once, /root/reference/src/fields/fq2_target.rs:401-428
-__global__ __launch_bounds__(64) void fq2_sqrt_kernel(const u32* x, const uint8_t* sgn, int n, u32* out, uint8_t* err) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u32* xi = x + (size_t)i * 24;
-    bool ok = below_p(xi) && below_p(xi + 12);
-    const F2 a{to_mont(xi), to_mont(xi + 12)};
+// A square root of a in Fq2 = Fq[u]/(u^2 + 1); ok = false when a is not a square
+__device__ __noinline__ F2 sqrt_fq2(const F2& a, bool& ok) {
     F2 r;
     if (is_zero(a.c1)) {
         bool sq;
@@ -151,7 +146,20 @@ __global__ __launch_bounds__(64) void fq2_sqrt_kernel(const u32* x, const uint8_
         r = {x0, mul(a.c1, inv(add(x0, x0)))};
     }
     const F2 chk = sqr(r);
-    ok = ok && eq(chk.c0, a.c0) && eq(chk.c1, a.c1);
+    ok = eq(chk.c0, a.c0) && eq(chk.c1, a.c1);
+    return r;
+}
+
+// Fq2SqrtGenerator::run_once, /root/reference/src/fields/fq2_target.rs:401-428
+__global__ __launch_bounds__(64) void fq2_sqrt_kernel(const u32* x, const uint8_t* sgn, int n, u32* out, uint8_t* err) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32* xi = x + (size_t)i * 24;
+    bool ok = below_p(xi) && below_p(xi + 12);
+    const F2 a{to_mont(xi), to_mont(xi + 12)};
+    bool is_square;
+    const F2 r = sqrt_fq2(a, is_square);
+    ok = ok && is_square;
     F r0 = from_mont(r.c0), r1 = from_mont(r.c1);
     const bool want = sgn[i] & 1u;
     auto sgn0_2 = [&](const F& c0, const F& c1) { return sgn0(c0) || (is_zero(c0) && sgn0(c1)); };

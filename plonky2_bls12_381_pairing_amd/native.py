@@ -278,6 +278,61 @@ class Context:
         check(rc)
         return out
 
+    # ---- compressed points and aggregation (ark-bls12-381 deserialize_compressed / serialize_compressed)
+    def _decompress(self, fn, data, nbytes, cols, check_subgroup, return_status):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        if data.ndim != 2 or data.shape[1] != nbytes:
+            raise ValueError("expected shape (n, %d)" % nbytes)
+        n = data.shape[0]
+        out = np.zeros((n, cols), dtype=np.uint64)
+        status = np.zeros(n, dtype=np.uint8)
+        rc = fn(self._h, _p8(data), n, 1 if check_subgroup else 0, _p64(out), _p8(status))
+        if return_status:
+            return out, status
+        check(rc)
+        return out, status
+
+    def g1_decompress_batch(self, data, check_subgroup=True, return_status=False):
+        """(n, 48) bytes -> ((n, 12) u64 affine points, (n,) status); raises on a rejected point unless
+        return_status."""
+        return self._decompress(lib.bls381_g1_decompress_batch, data, 48, 12, check_subgroup, return_status)
+
+    def g2_decompress_batch(self, data, check_subgroup=True, return_status=False):
+        return self._decompress(lib.bls381_g2_decompress_batch, data, 96, 24, check_subgroup, return_status)
+
+    def _compress(self, fn, pts, cols, nbytes, inf):
+        pts = _arr64(pts, cols)
+        n = pts.shape[0]
+        out = np.zeros((n, nbytes), dtype=np.uint8)
+        inf = _flags(inf, n)
+        check(fn(self._h, _p64(pts), _p8(inf), n, _p8(out)))
+        return out
+
+    def g1_compress_batch(self, g1, inf=None):
+        return self._compress(lib.bls381_g1_compress_batch, g1, 12, 48, inf)
+
+    def g2_compress_batch(self, g2, inf=None):
+        return self._compress(lib.bls381_g2_compress_batch, g2, 24, 96, inf)
+
+    def _aggregate(self, fn, pts, cols, group_size, inf):
+        pts = _arr64(pts, cols)
+        n = pts.shape[0]
+        if group_size <= 0 or n % group_size:
+            raise ValueError("the number of points must be a multiple of group_size")
+        groups = n // group_size
+        out = np.zeros((groups, cols), dtype=np.uint64)
+        out_inf = np.zeros(groups, dtype=np.uint8)
+        inf = _flags(inf, n)
+        check(fn(self._h, _p64(pts), _p8(inf), groups, group_size, _p64(out), _p8(out_inf)))
+        return out, out_inf
+
+    def g1_aggregate_batch(self, g1, group_size, inf=None):
+        """Sum of each run of group_size points -> ((groups, 12) u64, (groups,) infinity flags)."""
+        return self._aggregate(lib.bls381_g1_aggregate_batch, g1, 12, group_size, inf)
+
+    def g2_aggregate_batch(self, g2, group_size, inf=None):
+        return self._aggregate(lib.bls381_g2_aggregate_batch, g2, 24, group_size, inf)
+
     def pairing_witness_batch(self, g1, g2):
         g1, g2 = _arr64(g1, 12), _arr64(g2, 24)
         n = g1.shape[0]

@@ -16,6 +16,10 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pai
 
 @pytest.fixture(scope="module")
 def ctx():
+    # PyTorch-ROCm ships its own HIP runtime; when both runtimes live in one process torch's has to
+    # come up first (the other order leaves torch without a device on some hosts)
+    import torch
+    torch.cuda.init()
     import plonky2_bls12_381_pairing_amd as B
     c = B.Context(0)
     yield c
@@ -426,3 +430,118 @@ def test_other_lane_group_geometries(lanes, slots):
         prep = c.g2_prepared(g2[2])
         assert np.array_equal(c.pairing_fixed_q_batch(prep, g1[2:3]), out[2:3])
         prep.close()
+
+
+def _bytes_array(encodings):
+    return np.frombuffer(b"".join(encodings), dtype=np.uint8).reshape(len(encodings), -1)
+
+
+def test_compressed_points_and_aggregation(ctx):
+    """Wire format and aggregation against the big-integer oracle: every decoded limb, status byte,
+    encoded byte and aggregate is compared; the device's endomorphism subgroup tests are checked
+    against [r]P = O on curve points inside and outside the subgroup."""
+    import random
+    import bls381_points as PT
+    rng = random.Random(2024)
+    ks = [rng.randrange(1, R.R_ORDER) for _ in range(6)]
+    g1s = [R.G1_GEN] + [R.g1_mul(R.G1_GEN, k) for k in ks] + [R.g1_neg(R.g1_mul(R.G1_GEN, ks[0])), None]
+    g2s = [R.G2_GEN] + [R.g2_mul(R.G2_GEN, k) for k in ks[:3]] + [R.g2_neg(R.g2_mul(R.G2_GEN, ks[0])), None]
+
+    # ---- G1 decode
+    enc = [PT.g1_compress(p) for p in g1s]
+    assert enc[0] == PT.G1_GEN_COMPRESSED
+    bad = []
+    b = bytearray(PT.G1_GEN_COMPRESSED); b[0] &= 0x7F; bad.append(bytes(b))           # not the compressed form
+    bad.append(bytes([0xE0]) + bytes(47))                                            # infinity + sort flag
+    bad.append(bytes([0xC0]) + bytes(46) + b"\x01")                                  # infinity with x != 0
+    tb = bytearray(R.P.to_bytes(48, "big")); tb[0] |= 0x80; bad.append(bytes(tb))     # x = p
+    one = bytearray((1).to_bytes(48, "big")); one[0] |= 0x80; bad.append(bytes(one))  # 5 is not a square
+    outside = []
+    x = 4
+    while len(outside) < 3:
+        if R.fq_sqrt((x ** 3 + 4) % R.P) is not None:
+            e = bytearray(x.to_bytes(48, "big")); e[0] |= 0x80 | (0x20 if len(outside) % 2 else 0)
+            outside.append(bytes(e))
+        x += 1
+    allenc = enc + bad + outside
+    for check in (True, False):
+        want = [PT.g1_decompress(e, check_subgroup=check) for e in allenc]
+        out, status = ctx.g1_decompress_batch(_bytes_array(allenc), check_subgroup=check, return_status=True)
+        assert status.tolist() == [s for s, _ in want]
+        assert np.array_equal(out, H.g1_array([p for _, p in want]))
+    assert [s for s, _ in [PT.g1_decompress(e) for e in outside]] == [PT.NOT_IN_SUBGROUP] * 3
+    with pytest.raises(Exception, match="subgroup"):
+        ctx.g1_decompress_batch(_bytes_array(outside))
+    good, status = ctx.g1_decompress_batch(_bytes_array(enc))
+    assert np.array_equal(good, H.g1_array(g1s)) and status.tolist() == [0] * (len(g1s) - 1) + [1]
+
+    # ---- G2 decode
+    enc2 = [PT.g2_compress(q) for q in g2s]
+    assert enc2[0] == PT.G2_GEN_COMPRESSED
+    bad2 = []
+    b = bytearray(PT.G2_GEN_COMPRESSED); b[0] &= 0x7F; bad2.append(bytes(b))
+    bad2.append(bytes([0xC0]) + bytes(94) + b"\x01")
+    tb = bytearray(bytes(48) + R.P.to_bytes(48, "big")); tb[0] |= 0x80; bad2.append(bytes(tb))   # x.c0 = p
+    outside2, off_curve2 = [], []
+    x0 = 1
+    while len(outside2) < 2 or len(off_curve2) < 1:
+        xx = (x0, 1)
+        rhs = R.fq2_add(R.fq2_mul(R.fq2_square(xx), xx), (4, 4))
+        e = bytearray((1).to_bytes(48, "big") + x0.to_bytes(48, "big")); e[0] |= 0x80
+        if R.fq2_pow(rhs, (R.P * R.P - 1) // 2) == R.FQ2_ONE:
+            if len(outside2) < 2:
+                outside2.append(bytes(e))
+        elif len(off_curve2) < 1:
+            off_curve2.append(bytes(e))
+        x0 += 1
+    allenc2 = enc2 + bad2 + off_curve2 + outside2
+    for check in (True, False):
+        want = [PT.g2_decompress(e, check_subgroup=check) for e in allenc2]
+        out, status = ctx.g2_decompress_batch(_bytes_array(allenc2), check_subgroup=check, return_status=True)
+        assert status.tolist() == [s for s, _ in want]
+        assert np.array_equal(out, H.g2_array([q for _, q in want]))
+    assert PT.g2_decompress(outside2[0])[0] == PT.NOT_IN_SUBGROUP and PT.g2_decompress(off_curve2[0])[0] == PT.NOT_ON_CURVE
+
+    # ---- encode
+    inf1 = np.array([1 if p is None else 0 for p in g1s], dtype=np.uint8)
+    assert ctx.g1_compress_batch(H.g1_array(g1s), inf1).tobytes() == b"".join(enc)
+    inf2 = np.array([1 if q is None else 0 for q in g2s], dtype=np.uint8)
+    assert ctx.g2_compress_batch(H.g2_array(g2s), inf2).tobytes() == b"".join(enc2)
+
+    # ---- aggregation: groups of 1, 2, 7 and 512 points, with infinity members, repeats and opposite points
+    base = [R.g1_mul(R.G1_GEN, k) for k in range(1, 9)]
+    for size in (1, 2, 7, 512):
+        groups = []
+        for g in range(3):
+            members = [base[rng.randrange(8)] for _ in range(size)]
+            if size >= 2 and g == 1:
+                members[0] = None
+                members[1] = members[-1]                      # a repeated point: the doubling case
+            if size == 2 and g == 2:
+                members = [base[3], R.g1_neg(base[3])]        # sums to infinity
+            groups.append(members)
+        flat = [p for grp in groups for p in grp]
+        inf = np.array([1 if p is None else 0 for p in flat], dtype=np.uint8)
+        out, out_inf = ctx.g1_aggregate_batch(H.g1_array(flat), size, inf)
+        want = [PT.g1_aggregate(grp) for grp in groups]
+        assert out_inf.tolist() == [1 if w is None else 0 for w in want]
+        assert np.array_equal(out, H.g1_array(want))
+    base2 = [R.g2_mul(R.G2_GEN, k) for k in range(1, 5)]
+    for size in (1, 5, 64):
+        groups = [[base2[rng.randrange(4)] for _ in range(size)] for _ in range(2)]
+        if size >= 5:
+            groups[1][2] = None
+            groups[1][3] = R.g2_neg(groups[1][4])
+        flat = [q for grp in groups for q in grp]
+        inf = np.array([1 if q is None else 0 for q in flat], dtype=np.uint8)
+        out, out_inf = ctx.g2_aggregate_batch(H.g2_array(flat), size, inf)
+        want = [PT.g2_aggregate(grp) for grp in groups]
+        assert out_inf.tolist() == [1 if w is None else 0 for w in want]
+        assert np.array_equal(out, H.g2_array(want))
+    # decoded keys feed the pairing: e(sum of keys, Q) against the oracle
+    keys = [R.g1_mul(R.G1_GEN, k) for k in (2, 3, 5)]
+    dec, _ = ctx.g1_decompress_batch(_bytes_array([PT.g1_compress(p) for p in keys]))
+    agg, agg_inf = ctx.g1_aggregate_batch(dec, 3)
+    assert agg_inf.tolist() == [0]
+    got = ctx.pairing_batch(agg, H.g2_array([R.G2_GEN]))
+    assert H.fq12_from_row(got[0]) == R.native_pairing([R.g1_mul(R.G1_GEN, 10)], [R.G2_GEN])

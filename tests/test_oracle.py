@@ -191,3 +191,46 @@ def test_c_oracle_optimised_variant_gives_the_same_values():
     finally:
         CO.set_fast(False)
     assert np.array_equal(ref, fast)
+
+
+def test_point_format_oracle():
+    """Compressed encodings: the generators' well-known byte strings, round trips, rejections, and the
+    order-r test against curve points outside the subgroup."""
+    import random
+    import bls381_points as PT
+    assert PT.g1_compress(R.G1_GEN) == PT.G1_GEN_COMPRESSED
+    assert PT.g2_compress(R.G2_GEN) == PT.G2_GEN_COMPRESSED
+    assert PT.g1_decompress(PT.G1_GEN_COMPRESSED) == (PT.OK, R.G1_GEN)
+    assert PT.g2_decompress(PT.G2_GEN_COMPRESSED) == (PT.OK, R.G2_GEN)
+    assert PT.g1_decompress(PT.g1_compress(None)) == (PT.INFINITY, None)
+    assert PT.g2_decompress(PT.g2_compress(None)) == (PT.INFINITY, None)
+    rng = random.Random(11)
+    for _ in range(3):
+        k = rng.randrange(1, R.R_ORDER)
+        for p in (R.g1_mul(R.G1_GEN, k), R.g1_neg(R.g1_mul(R.G1_GEN, k))):
+            assert PT.g1_decompress(PT.g1_compress(p)) == (PT.OK, p)
+        for q in (R.g2_mul(R.G2_GEN, k), R.g2_neg(R.g2_mul(R.G2_GEN, k))):
+            assert PT.g2_decompress(PT.g2_compress(q)) == (PT.OK, q)
+    # rejections
+    b = bytearray(PT.G1_GEN_COMPRESSED); b[0] &= 0x7F
+    assert PT.g1_decompress(bytes(b))[0] == PT.BAD_ENCODING          # uncompressed flag
+    assert PT.g1_decompress(bytes([0xE0]) + bytes(47))[0] == PT.BAD_ENCODING   # infinity with the sort flag
+    assert PT.g1_decompress(bytes([0xC0]) + bytes(46) + b"\x01")[0] == PT.BAD_ENCODING
+    too_big = bytearray(R.P.to_bytes(48, "big")); too_big[0] |= 0x80
+    assert PT.g1_decompress(bytes(too_big))[0] == PT.BAD_ENCODING    # x = p
+    # x = 1: 1 + 4 = 5 is not a square mod p
+    assert R.fq_sqrt(5) is None
+    one = bytearray((1).to_bytes(48, "big")); one[0] |= 0x80
+    assert PT.g1_decompress(bytes(one))[0] == PT.NOT_ON_CURVE
+    # a curve point outside the subgroup passes without the check and fails with it
+    x = 4
+    while R.fq_sqrt((x ** 3 + 4) % R.P) is None:
+        x += 1
+    enc = bytearray(x.to_bytes(48, "big")); enc[0] |= 0x80
+    st, pt = PT.g1_decompress(bytes(enc), check_subgroup=False)
+    assert st == PT.OK and R.g1_on_curve(pt) and not PT.g1_in_subgroup(pt)
+    assert PT.g1_decompress(bytes(enc))[0] == PT.NOT_IN_SUBGROUP
+    # aggregation is the group law
+    pts = [R.g1_mul(R.G1_GEN, k) for k in (3, 5, 9)]
+    assert PT.g1_aggregate(pts) == R.g1_mul(R.G1_GEN, 17)
+    assert PT.g1_aggregate([pts[0], R.g1_neg(pts[0])]) is None

@@ -1,0 +1,40 @@
+"""Timing of the wire-format and aggregation calls (host buffers in and out, copies included)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+import numpy as np
+import helpers as H
+import bls381_ref as R
+import bls381_points as PT
+import plonky2_bls12_381_pairing_amd as B
+
+ctx = B.Context(0)
+base1 = [R.g1_mul(R.G1_GEN, k) for k in range(1, 65)]
+base2 = [R.g2_mul(R.G2_GEN, k) for k in range(1, 65)]
+e1 = np.frombuffer(b"".join(PT.g1_compress(p) for p in base1), dtype=np.uint8).reshape(64, 48)
+e2 = np.frombuffer(b"".join(PT.g2_compress(q) for q in base2), dtype=np.uint8).reshape(64, 96)
+
+
+def timed(label, fn, n, reps=3):
+    fn()
+    best = min((lambda t0: (fn(), time.perf_counter() - t0)[1])(time.perf_counter()) for _ in range(reps))
+    print("%-46s n=%7d  %8.2f ms  %10.0f /s" % (label, n, best * 1e3, n / best), flush=True)
+
+
+for n in (65536,):
+    d1 = np.tile(e1, (n // 64, 1))
+    d2 = np.tile(e2, (n // 64, 1))
+    timed("G1 decode, on-curve only", lambda: ctx.g1_decompress_batch(d1, check_subgroup=False), n)
+    timed("G1 decode + subgroup test", lambda: ctx.g1_decompress_batch(d1, check_subgroup=True), n)
+    timed("G2 decode, on-curve only", lambda: ctx.g2_decompress_batch(d2, check_subgroup=False), n)
+    timed("G2 decode + subgroup test", lambda: ctx.g2_decompress_batch(d2, check_subgroup=True), n)
+    p1, _ = ctx.g1_decompress_batch(d1, check_subgroup=False)
+    p2, _ = ctx.g2_decompress_batch(d2, check_subgroup=False)
+    timed("G1 encode", lambda: ctx.g1_compress_batch(p1), n)
+    timed("G2 encode", lambda: ctx.g2_compress_batch(p2), n)
+    timed("G1 aggregate, 128 groups of 512 keys", lambda: ctx.g1_aggregate_batch(p1, 512), n)
+    timed("G1 aggregate, 1 group of 512 keys", lambda: ctx.g1_aggregate_batch(p1[:512], 512), 512)
+    timed("G2 aggregate, 128 groups of 512 signatures", lambda: ctx.g2_aggregate_batch(p2, 512), n)
