@@ -84,6 +84,22 @@ int bls381_multi_pairing(bls381_ctx*, const uint64_t* g1, const uint64_t* g2, co
  * the gather in a multi-GPU multi-pairing.  partials: n_partials x 72 u64. */
 int bls381_finish_multi_pairing(bls381_ctx*, const uint64_t* partials, size_t n_partials, uint64_t out_fq12[72],
                                 int* is_one);
+/* native_pairing(&[pa, pb], &[qa, qb]) for each of n independent items: two pairs share one Miller
+ * accumulator, as multi_miller_loop_native runs a chunk of pairs (src/native/miller_loop.rs:139-156),
+ * then one final exponentiation (src/native/pairing.rs:8-13).  This is the shape of a signature
+ * check, e(pk, H(m)) * e(-G1, sig) == 1: is_one (may be NULL) receives 1 per item whose result is
+ * Fq12::ONE; out_fq12 may be NULL when only is_one is wanted.  inf_flags (may be NULL): one byte per
+ * item, bit 0 pa / bit 1 qa / bit 2 pb / bit 3 qb is infinity; such a pair is left out of the
+ * product, as the filter at :130-136 does.  The first form stops before the final exponentiation. */
+int bls381_miller_loop_two_pairs_batch(bls381_ctx*, const uint64_t* g1a, const uint64_t* g2a, const uint64_t* g1b,
+                                       const uint64_t* g2b, const uint8_t* inf_flags, size_t n, uint64_t* out_fq12);
+int bls381_pairing_two_pairs_batch(bls381_ctx*, const uint64_t* g1a, const uint64_t* g2a, const uint64_t* g1b,
+                                   const uint64_t* g2b, const uint8_t* inf_flags, size_t n, uint64_t* out_fq12,
+                                   uint8_t* is_one);
+/* The same on device memory. */
+int bls381_pairing_two_pairs_batch_dev(bls381_ctx*, const uint64_t* g1a_dev, const uint64_t* g2a_dev,
+                                       const uint64_t* g1b_dev, const uint64_t* g2b_dev, const uint8_t* inf_flags_dev,
+                                       size_t n, uint64_t* out_fq12_dev, uint8_t* is_one_dev);
 /* G2Prepared::from(q).ell_coeffs for n points (src/native/miller_loop.rs:90-119):
  * out_coeffs = n x 68 x 3 Fq2 = n x 68 x 36 u64. */
 int bls381_g2_prepare_batch(bls381_ctx*, const uint64_t* g2, size_t n, uint64_t* out_coeffs);
@@ -130,7 +146,7 @@ int bls381_final_exp_batch_dev(bls381_ctx*, const uint64_t* in_fq12_dev, size_t 
                                uint8_t* is_zero_err_dev);
 
 /* Introspection used by the tests and the benchmark. */
-/* Builds and schedules the step program `which` ("miller", "fe1", "fe2", "g2prep", "ell", "fq12mul",
+/* Builds and schedules the step program `which` ("miller", "millerfq", "miller2", "fe1", "fe2", "g2prep", "ell", "fq12mul",
  * "easy2", "hardgen", "inv1", "inv2", "frob1", "frob2") for groups of K lanes and copies it into
  * caller buffers: hdrs = nsteps x 2 u32, descs = nsteps x K x 8 u32.  info[8] receives
  * {K, nsteps, lds_slots, tmp_slots, n_in, n_out, multiply-accumulates executed (300 per product, 444 per two-product sum), n_lin}.  Pass NULL buffers to query sizes.

@@ -52,6 +52,7 @@ static Dag build_named(const std::string& which) {
     if (which == "miller") return build_miller();
     if (which == "g2prep") return build_g2_prepare();
     if (which == "millerfq") return build_miller_fixed_q();
+    if (which == "miller2") return build_miller_two_pairs();
     if (which == "ell") return build_ell();
     if (which == "fe1") return build_final_exp_part1();
     if (which == "fe2") return build_final_exp_part2(true);
@@ -64,7 +65,7 @@ static Dag build_named(const std::string& which) {
     if (which == "frob2") return build_frobenius(2);
     throw std::runtime_error("unknown program " + which);
 }
-static const char* ALL_PROGRAMS[] = {"miller", "millerfq", "g2prep", "ell",  "fe1",     "fe2",   "easy2",
+static const char* ALL_PROGRAMS[] = {"miller", "millerfq", "miller2", "g2prep", "ell",  "fe1",     "fe2",   "easy2",
                                      "hardgen", "inv1",   "inv2", "fq12mul", "frob1", "frob2"};
 
 static bool valid_k(int K) { return K == 6 || K == 8 || K == 9 || K == 12 || K == 16; }
@@ -118,7 +119,7 @@ struct bls381_ctx {
     uint4* d_vmconsts = nullptr;
     unsigned long long* d_prof = nullptr;  // set while bls381_debug_profile runs
     const uint4* consts_override = nullptr;  // set while a program runs against a prepared G2 point's table
-    DevBuf user_in, user_in2, user_in3, user_out, flags, bufA, bufB, bufC, bufTmp, zflags;
+    DevBuf user_in, user_in2, user_in3, user_in4, user_out, flags, bufA, bufB, bufC, bufD, bufE, bufTmp, zflags;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float last_ms[4] = {0, 0, 0, 0};  // Miller kernel, fe1 + inversion, fe2 kernel, whole device call
     std::mutex mu;
@@ -129,9 +130,11 @@ struct bls381_ctx {
 // Lane-group width per program.  Measured on MI355X (65,536 pairings): with the two-product
 // multiplier steps 8 lanes per pairing is best for both the Miller loop (16.1 ms vs 16.6 ms at 16
 // lanes) and the final exponentiation (22.7 vs 24.3 ms), so every program uses the context's K.
+// The two-pair Miller loop is the exception: with twice the independent work per item it fills 16
+// lanes (17.4 ms against 18.5 ms at 8), and is run that way when the context uses the defaults.
 static void program_geometry(const bls381_ctx* c, const std::string& which, int& K, int& slots) {
-    (void)which;
     K = c->K; slots = c->lds_slots;
+    if (c->auto_geometry && which == "miller2") { K = 16; slots = default_slots(16); }
 }
 
 // Synthetic programs for timing one step kind in isolation: 1,000 identical steps with every lane
@@ -238,8 +241,8 @@ extern "C" void bls381_ctx_destroy(bls381_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (auto& kv : c->progs) (void)hipFree(kv.second.d_blocks);
-    for (DevBuf* b : {&c->user_in, &c->user_in2, &c->user_in3, &c->user_out, &c->flags, &c->bufA, &c->bufB, &c->bufC,
-                      &c->bufTmp, &c->zflags})
+    for (DevBuf* b : {&c->user_in, &c->user_in2, &c->user_in3, &c->user_in4, &c->user_out, &c->flags, &c->bufA, &c->bufB,
+                      &c->bufC, &c->bufD, &c->bufE, &c->bufTmp, &c->zflags})
         b->release();
     c->wit.release();
     if (c->d_consts) (void)hipFree(c->d_consts);
@@ -367,6 +370,67 @@ static int miller_dev_locked(bls381_ctx* c, const uint64_t* g1, const uint64_t* 
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     if (n) {  // timings of the last chunk
+        (void)hipEventElapsedTime(&c->last_ms[0], c->ev[1], c->ev[2]);
+        (void)hipEventElapsedTime(&c->last_ms[1], c->ev[2], c->ev[3]);
+        (void)hipEventElapsedTime(&c->last_ms[2], c->ev[3], c->ev[4]);
+        (void)hipEventElapsedTime(&c->last_ms[3], c->ev[0], c->ev[5]);
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ two pairs per item
+// native_pairing(&[pa, pb], &[qa, qb]) for n independent items, all pointers device memory.
+// flags: one byte per item, bit 0 pa / bit 1 qa / bit 2 pb / bit 3 qb is infinity (may be null).
+static int two_pairs_dev_locked(bls381_ctx* c, const uint64_t* g1a, const uint64_t* g2a, const uint64_t* g1b,
+                                const uint64_t* g2b, const uint8_t* flags, size_t n, uint64_t* out, uint8_t* is_one,
+                                bool with_final_exp) {
+    std::vector<uint8_t> hflags;
+    if (flags) {
+        hflags.resize(n);
+        HIPCHK(hipMemcpyAsync(hflags.data(), flags, n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    for (size_t off = 0; off < n; off += CHUNK) {
+        int m = (int)std::min<size_t>(CHUNK, n - off);
+        int npad = pad_elems(m);
+        HIPCHK(c->bufA.ensure(soa_bytes(12, npad)));
+        HIPCHK(c->bufB.ensure(soa_bytes(12, npad)));
+        HIPCHK(hipEventRecord(c->ev[0], c->stream));
+        int rc;
+        if ((rc = pack(c, g1a + off * 12, c->bufA.p, m, npad, 2, 0))) return rc;
+        if ((rc = pack(c, g2a + off * 24, c->bufA.p, m, npad, 4, 2))) return rc;
+        if ((rc = pack(c, g1b + off * 12, c->bufA.p, m, npad, 2, 6))) return rc;
+        if ((rc = pack(c, g2b + off * 24, c->bufA.p, m, npad, 4, 8))) return rc;
+        HIPCHK(hipEventRecord(c->ev[1], c->stream));
+        if ((rc = run_program(c, "miller2", c->bufA.p, c->bufB.p, m, npad))) return rc;
+        bool any = false;
+        for (int i = 0; flags && i < m; i++) any = any || (hflags[off + i] & 15u);
+        if (any) {  // rare: the pairs' own Miller values for the items that skip one
+            HIPCHK(c->bufD.ensure(soa_bytes(12, npad)));
+            HIPCHK(c->bufE.ensure(soa_bytes(12, npad)));
+            if ((rc = run_program(c, "miller", c->bufA.p, c->bufD.p, m, npad))) return rc;
+            if ((rc = run_program(c, "miller", (const char*)c->bufA.p + soa_bytes(6, npad), c->bufE.p, m, npad))) return rc;
+            hipLaunchKernelGGL(select_two_pairs, dim3((m + 255) / 256), dim3(256), 0, c->stream, (uint4*)c->bufB.p,
+                               (const uint4*)c->bufD.p, (const uint4*)c->bufE.p, flags + off, c->d_consts, m, npad);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipEventRecord(c->ev[2], c->stream));
+        if (with_final_exp) {
+            if ((rc = final_exp_soa(c, c->bufB.p, c->bufB.p, m, npad, nullptr))) return rc;
+        } else {
+            HIPCHK(hipEventRecord(c->ev[3], c->stream));
+        }
+        HIPCHK(hipEventRecord(c->ev[4], c->stream));
+        if (is_one) {
+            hipLaunchKernelGGL(is_one_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, (const uint4*)c->bufB.p,
+                               c->d_consts, m, npad, is_one + off);
+            HIPCHK(hipGetLastError());
+        }
+        if (out && (rc = unpack(c, c->bufB.p, out + off * 72, m, npad, 12, 0))) return rc;
+        HIPCHK(hipEventRecord(c->ev[5], c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n) {
         (void)hipEventElapsedTime(&c->last_ms[0], c->ev[1], c->ev[2]);
         (void)hipEventElapsedTime(&c->last_ms[1], c->ev[2], c->ev[3]);
         (void)hipEventElapsedTime(&c->last_ms[2], c->ev[3], c->ev[4]);
@@ -651,6 +715,50 @@ extern "C" int bls381_pairing_batch(bls381_ctx* c, const uint64_t* g1, const uin
                                     uint64_t* out) {
     CTX_GUARD(c);
     return pairs_host(c, g1, g2, flags, n, out, true);
+}
+
+static int two_pairs_host(bls381_ctx* c, const uint64_t* g1a, const uint64_t* g2a, const uint64_t* g1b, const uint64_t* g2b,
+                          const uint8_t* flags, size_t n, uint64_t* out, uint8_t* is_one, bool fe) {
+    if (n && (!g1a || !g2a || !g1b || !g2b || (!out && !is_one))) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    if (n == 0) return 0;
+    int rc;
+    if ((rc = h2d(c, c->user_in, g1a, n * 96))) return rc;
+    if ((rc = h2d(c, c->user_in2, g2a, n * 192))) return rc;
+    if ((rc = h2d(c, c->user_in3, g1b, n * 96))) return rc;
+    if ((rc = h2d(c, c->user_in4, g2b, n * 192))) return rc;
+    const uint8_t* fdev = nullptr;
+    if (flags) {
+        if ((rc = h2d(c, c->flags, flags, n))) return rc;
+        fdev = (const uint8_t*)c->flags.p;
+    }
+    if (out) HIPCHK(c->user_out.ensure(n * 576));
+    if (is_one) HIPCHK(c->zflags.ensure(n));
+    rc = two_pairs_dev_locked(c, (const uint64_t*)c->user_in.p, (const uint64_t*)c->user_in2.p, (const uint64_t*)c->user_in3.p,
+                              (const uint64_t*)c->user_in4.p, fdev, n, out ? (uint64_t*)c->user_out.p : nullptr,
+                              is_one ? (uint8_t*)c->zflags.p : nullptr, fe);
+    if (rc) return rc;
+    if (out) HIPCHK(hipMemcpy(out, c->user_out.p, n * 576, hipMemcpyDeviceToHost));
+    if (is_one) HIPCHK(hipMemcpy(is_one, c->zflags.p, n, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int bls381_miller_loop_two_pairs_batch(bls381_ctx* c, const uint64_t* g1a, const uint64_t* g2a, const uint64_t* g1b,
+                                                  const uint64_t* g2b, const uint8_t* flags, size_t n, uint64_t* out) {
+    CTX_GUARD(c);
+    if (n && !out) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    return two_pairs_host(c, g1a, g2a, g1b, g2b, flags, n, out, nullptr, false);
+}
+extern "C" int bls381_pairing_two_pairs_batch(bls381_ctx* c, const uint64_t* g1a, const uint64_t* g2a, const uint64_t* g1b,
+                                              const uint64_t* g2b, const uint8_t* flags, size_t n, uint64_t* out,
+                                              uint8_t* is_one) {
+    CTX_GUARD(c);
+    return two_pairs_host(c, g1a, g2a, g1b, g2b, flags, n, out, is_one, true);
+}
+extern "C" int bls381_pairing_two_pairs_batch_dev(bls381_ctx* c, const uint64_t* g1a, const uint64_t* g2a, const uint64_t* g1b,
+                                                  const uint64_t* g2b, const uint8_t* flags, size_t n, uint64_t* out,
+                                                  uint8_t* is_one) {
+    CTX_GUARD(c);
+    if (n && (!g1a || !g2a || !g1b || !g2b || (!out && !is_one))) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    return two_pairs_dev_locked(c, g1a, g2a, g1b, g2b, flags, n, out, is_one, true);
 }
 
 static int fe_host(bls381_ctx* c, const uint64_t* in, size_t n, uint64_t* out, uint8_t* zero, const char* part2) {

@@ -366,6 +366,36 @@ Dag build_miller() {
     return d;
 }
 
+// Two pairs sharing one accumulator, as multi_miller_loop_native runs a chunk of pairs
+// (/root/reference/src/native/miller_loop.rs:139-156): f is squared once per bit, then multiplied by
+// each pair's line.  Equal, as a field element, to the product of the two single-pair values.
+// gin: P1 (2), Q1 (4), P2 (2), Q2 (4).
+Dag build_miller_two_pairs() {
+    Dag d;
+    d.n_in = 12; d.n_out = 12;
+    Tower T(d);
+    SFq12 f = T.one12();
+    SFp px[2], py[2];
+    SFq2 qx[2], qy[2];
+    Tower::G2Proj r[2];
+    for (int j = 0; j < 2; j++) {
+        const int b = 6 * j;
+        px[j] = T.in(b); py[j] = T.in(b + 1);
+        qx[j] = SFq2{T.in(b + 2), T.in(b + 3)}; qy[j] = SFq2{T.in(b + 4), T.in(b + 5)};
+        r[j] = Tower::G2Proj{qx[j], qy[j], T.one2()};
+    }
+    for (int i = 62; i >= 0; i--) {
+        f = T.sqr(f);
+        for (int j = 0; j < 2; j++) f = T.ell(f, T.g2_double(r[j], T.cst(C_TWO_INV)), px[j], py[j]);
+        if ((BLS381_X >> i) & 1)
+            for (int j = 0; j < 2; j++) f = T.ell(f, T.g2_add(r[j], qx[j], qy[j]), px[j], py[j]);
+    }
+    f = T.conj(f);
+    T.out12(f, 0);
+    d.optimise();
+    return d;
+}
+
 // Miller loop against line coefficients prepared once (G2Prepared::ell_coeffs reused for many P,
 // /root/reference/src/native/miller_loop.rs:13-16, 139-156): the 68 coefficients are constants
 // C_COUNT + 6 k + {c0.c0, c0.c1, c1.c0, c1.c1, c2.c0, c2.c1}, only f is computed.  gin: G1 (2).

@@ -363,6 +363,36 @@ __global__ void set_one_where_flag(uint4* soa, const uint8_t* flags, const uint4
     }
 }
 
+// Two-pair items with a pair at infinity: bits 0..1 of flags[e] skip the first pair, bits 2..3 the
+// second.  Both skipped -> one; one skipped -> the other pair's own Miller value (only_a / only_b).
+__global__ void select_two_pairs(uint4* soa, const uint4* only_a, const uint4* only_b, const uint8_t* flags,
+                                 const uint4* consts, int n, int npad) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const bool skip_a = flags[e] & 3u, skip_b = flags[e] & 12u;
+    if (!skip_a && !skip_b) return;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (int f = 0; f < 12; f++)
+        for (int k = 0; k < 3; k++) {
+            const size_t at = ((size_t)f * 3 + k) * npad + e;
+            if (skip_a && skip_b) soa[at] = f == 0 ? consts[C_ONE * 3 + k] : z;
+            else soa[at] = skip_a ? only_b[at] : only_a[at];
+        }
+}
+// flags[e] = 1 when the Fq12 in slots 0..11 equals one
+__global__ void is_one_kernel(const uint4* soa, const uint4* consts, int n, int npad, uint8_t* flags) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    u32 diff = 0;
+    for (int f = 0; f < 12; f++)
+        for (int k = 0; k < 3; k++) {
+            const uint4 v = soa[((size_t)f * 3 + k) * npad + e];
+            const uint4 w = f == 0 ? consts[C_ONE * 3 + k] : make_uint4(0, 0, 0, 0);
+            diff |= (v.x ^ w.x) | (v.y ^ w.y) | (v.z ^ w.z) | (v.w ^ w.w);
+        }
+    flags[e] = diff == 0 ? 1 : 0;
+}
+
 // dst (24 slots, stride npad_dst) element i = (src[i], i + h < m ? src[i + h] : one): one level of a product tree
 __global__ void tree_pack_kernel(const uint4* src, uint4* dst, const uint4* consts, int m, int h, int npad_src,
                                  int npad_dst) {

@@ -278,6 +278,29 @@ class Context:
         check(rc)
         return out
 
+    def _two_pairs(self, g1a, g2a, g1b, g2b, inf_flags, with_final_exp):
+        g1a, g2a, g1b, g2b = _arr64(g1a, 12), _arr64(g2a, 24), _arr64(g1b, 12), _arr64(g2b, 24)
+        n = g1a.shape[0]
+        if not (g2a.shape[0] == g1b.shape[0] == g2b.shape[0] == n):
+            raise ValueError("the four point arrays must have one row per item")
+        f = _flags(inf_flags, n)
+        out = np.zeros((n, 72), dtype=np.uint64)
+        if with_final_exp:
+            is_one = np.zeros(n, dtype=np.uint8)
+            check(lib.bls381_pairing_two_pairs_batch(self._h, _p64(g1a), _p64(g2a), _p64(g1b), _p64(g2b), _p8(f), n,
+                                                     _p64(out), _p8(is_one)))
+            return out, is_one
+        check(lib.bls381_miller_loop_two_pairs_batch(self._h, _p64(g1a), _p64(g2a), _p64(g1b), _p64(g2b), _p8(f), n, _p64(out)))
+        return out
+
+    def miller_loop_two_pairs_batch(self, g1a, g2a, g1b, g2b, inf_flags=None):
+        """multi_miller_loop_native([pa, pb], [qa, qb]) per item (native/miller_loop.rs:121-162)."""
+        return self._two_pairs(g1a, g2a, g1b, g2b, inf_flags, False)
+
+    def pairing_two_pairs_batch(self, g1a, g2a, g1b, g2b, inf_flags=None):
+        """native_pairing([pa, pb], [qa, qb]) per item -> ((n, 72) u64, (n,) result-is-one flags)."""
+        return self._two_pairs(g1a, g2a, g1b, g2b, inf_flags, True)
+
     # ---- compressed points and aggregation (ark-bls12-381 deserialize_compressed / serialize_compressed)
     def _decompress(self, fn, data, nbytes, cols, check_subgroup, return_status):
         data = np.ascontiguousarray(data, dtype=np.uint8)

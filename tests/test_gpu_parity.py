@@ -545,3 +545,41 @@ def test_compressed_points_and_aggregation(ctx):
     assert agg_inf.tolist() == [0]
     got = ctx.pairing_batch(agg, H.g2_array([R.G2_GEN]))
     assert H.fq12_from_row(got[0]) == R.native_pairing([R.g1_mul(R.G1_GEN, 10)], [R.G2_GEN])
+
+
+def test_two_pairs_per_item(ctx, CO):
+    """native_pairing over two pairs per item (the signature-check shape) against the oracle's
+    multi_miller_loop / native_pairing, with pairs at infinity, valid and invalid signatures."""
+    import random
+    rng = random.Random(77)
+    n = 9
+    pa, qa = H.random_pairs(n, 501)
+    pb, qb = H.random_pairs(n, 502)
+    flags = np.zeros(n, dtype=np.uint8)
+    pa[1] = None; flags[1] = 1           # first pair skipped
+    qb[2] = None; flags[2] = 8           # second pair skipped
+    pa[3] = None; qb[3] = None; flags[3] = 1 | 8   # both skipped -> one
+    # items 4, 5: a valid signature check  e(pk, H) * e(-G1, sk * H) = 1, item 6: a wrong signature
+    for i in (4, 5, 6):
+        sk, h = rng.randrange(1, R.R_ORDER), rng.randrange(1, R.R_ORDER)
+        hm = R.g2_mul(R.G2_GEN, h)
+        pa[i], qa[i] = R.g1_mul(R.G1_GEN, sk), hm
+        pb[i], qb[i] = R.g1_neg(R.G1_GEN), R.g2_mul(hm, sk if i != 6 else sk + 1)
+    arrs = (H.g1_array(pa), H.g2_array(qa), H.g1_array(pb), H.g2_array(qb))
+    ml = ctx.miller_loop_two_pairs_batch(*arrs, inf_flags=flags)
+    out, is_one = ctx.pairing_two_pairs_batch(*arrs, inf_flags=flags)
+    for i in range(n):
+        ps = [p for p, q in ((pa[i], qa[i]), (pb[i], qb[i])) if p is not None and q is not None]
+        qs = [q for p, q in ((pa[i], qa[i]), (pb[i], qb[i])) if p is not None and q is not None]
+        assert H.fq12_from_row(ml[i]) == R.multi_miller_loop(ps, qs), i
+        want = R.native_pairing(ps, qs)
+        assert H.fq12_from_row(out[i]) == want, i
+        assert bool(is_one[i]) == (want == R.FQ12_ONE)
+    assert is_one.tolist() == [0, 0, 0, 1, 1, 1, 0, 0, 0]
+    # a larger batch against the per-pair path: product of the two single Miller values, then the same final exponentiation
+    m = 2048 + 37
+    g1 = np.tile(arrs[0][[0, 7, 8]], (m // 3 + 1, 1))[:m]; g2 = np.tile(arrs[1][[0, 7, 8]], (m // 3 + 1, 1))[:m]
+    h1 = np.tile(arrs[2][[8, 0, 7]], (m // 3 + 1, 1))[:m]; h2 = np.tile(arrs[3][[8, 0, 7]], (m // 3 + 1, 1))[:m]
+    got, _ = ctx.pairing_two_pairs_batch(g1, g2, h1, h2)
+    prod = ctx.fq12_mul_batch(ctx.miller_loop_batch(g1, g2), ctx.miller_loop_batch(h1, h2))
+    assert np.array_equal(got, ctx.final_exponentiation_batch(prod))

@@ -123,6 +123,21 @@ def test_fixed_q_miller_program():
     assert prog["n_fmul"] < 0.8 * S.get_program("miller")["n_fmul"]
 
 
+def test_two_pair_miller_program():
+    """Two pairs on one accumulator against multi_miller_loop_native over both pairs."""
+    ps, qs = H.random_pairs(2, 991)
+    prog = S.get_program("miller2")
+    assert prog["n_in"] == 12 and prog["n_out"] == 12
+    gin = []
+    for p, q in zip(ps, qs):
+        gin += [M(p[0]), M(p[1]), M(q[0][0]), M(q[0][1]), M(q[1][0]), M(q[1][1])]
+    out = S.run_program(prog, gin)
+    assert R.fq12_from_flat_ark([F(x) for x in out]) == R.multi_miller_loop(ps, qs)
+    # one shared squaring chain: clearly fewer products than two single-pair loops
+    single = S.get_program("miller")
+    assert prog["n_fmul"] < 1.8 * single["n_fmul"]
+
+
 def test_program_statistics():
     """Multiplier work, counted in the work model's unit (12-limb multiply-accumulates: 300 per product,
     444 per two-product sum with its single reduction), stays within 2% of the reference work model
