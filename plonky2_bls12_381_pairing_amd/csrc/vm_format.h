@@ -62,7 +62,7 @@ struct OpDesc {
 };
 static_assert(sizeof(OpDesc) == 32, "OpDesc must be 32 bytes");
 
-enum { LIN_MAX_TERMS = 7, MAX_LDS_SLOTS = 128 };
+enum { LIN_MAX_TERMS = 7, MAX_LDS_SLOTS = 128 };  // seven 2^28-bounded digits and their carries fit 32 bits
 
 // ---- device encoding.  The interpreter reads 16-byte descriptors, 64 per 1 KiB block: a block
 // holds floor(64 / K) consecutive steps, the descriptor of (step j of the block, lane-in-group r)
@@ -103,7 +103,7 @@ inline PackedDesc pack_desc(const StepHdr& h, const OpDesc& d) {
         }
     }
     return p;
-}  // seven 2^28-bounded digits and their carries fit 32 bits
+}
 
 // Constant table ids (each entry 14 digits of 28 bits; Montgomery factor 2^392 unless noted).
 enum ConstId : uint32_t {

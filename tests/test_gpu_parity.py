@@ -583,3 +583,24 @@ def test_two_pairs_per_item(ctx, CO):
     got, _ = ctx.pairing_two_pairs_batch(g1, g2, h1, h2)
     prod = ctx.fq12_mul_batch(ctx.miller_loop_batch(g1, g2), ctx.miller_loop_batch(h1, h2))
     assert np.array_equal(got, ctx.final_exponentiation_batch(prod))
+
+
+def test_point_format_golden_vectors(ctx):
+    v = json.load(open(os.path.join(os.path.dirname(GOLDEN), "point_vectors.json")))
+    enc1 = [bytes.fromhex(c["g1_bytes"]) for c in v["cases"]] + [bytes.fromhex(v["infinity_g1"])]
+    enc2 = [bytes.fromhex(c["g2_bytes"]) for c in v["cases"]] + [bytes.fromhex(v["infinity_g2"])]
+    g1, st1 = ctx.g1_decompress_batch(_bytes_array(enc1))
+    g2, st2 = ctx.g2_decompress_batch(_bytes_array(enc2))
+    n = len(v["cases"])
+    assert st1.tolist() == [0] * n + [1] and st2.tolist() == [0] * n + [1]
+    want1 = [tuple(int(x, 16) for x in c["g1"]) for c in v["cases"]] + [None]
+    want2 = [((int(c["g2"][0], 16), int(c["g2"][1], 16)), (int(c["g2"][2], 16), int(c["g2"][3], 16))) for c in v["cases"]] + [None]
+    assert np.array_equal(g1, H.g1_array(want1)) and np.array_equal(g2, H.g2_array(want2))
+    assert ctx.g1_compress_batch(g1, st1).tobytes() == b"".join(enc1)
+    assert ctx.g2_compress_batch(g2, st2).tobytes() == b"".join(enc2)
+    s1, i1 = ctx.g1_aggregate_batch(g1, n + 1, st1)
+    s2, i2 = ctx.g2_aggregate_batch(g2, n + 1, st2)
+    assert ctx.g1_compress_batch(s1, i1).tobytes().hex() == v["sum_g1"]
+    assert ctx.g2_compress_batch(s2, i2).tobytes().hex() == v["sum_g2"]
+    _, st = ctx.g1_decompress_batch(_bytes_array([bytes.fromhex(e) for e in v["on_curve_outside_subgroup_g1"]]), return_status=True)
+    assert st.tolist() == [4, 4]

@@ -234,3 +234,23 @@ def test_point_format_oracle():
     pts = [R.g1_mul(R.G1_GEN, k) for k in (3, 5, 9)]
     assert PT.g1_aggregate(pts) == R.g1_mul(R.G1_GEN, 17)
     assert PT.g1_aggregate([pts[0], R.g1_neg(pts[0])]) is None
+
+
+def test_point_format_golden_vectors():
+    import json, os
+    import bls381_points as PT
+    v = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "point_vectors.json")))
+    assert bytes.fromhex(v["generator_g1"]) == PT.G1_GEN_COMPRESSED == PT.g1_compress(R.G1_GEN)
+    assert bytes.fromhex(v["generator_g2"]) == PT.G2_GEN_COMPRESSED == PT.g2_compress(R.G2_GEN)
+    p1, p2 = [], []
+    for c in v["cases"]:
+        st, p = PT.g1_decompress(bytes.fromhex(c["g1_bytes"]))
+        assert st == PT.OK and [int(x, 16) for x in c["g1"]] == list(p)
+        st, q = PT.g2_decompress(bytes.fromhex(c["g2_bytes"]))
+        assert st == PT.OK and [int(x, 16) for x in c["g2"]] == [q[0][0], q[0][1], q[1][0], q[1][1]]
+        assert p == R.g1_mul(R.G1_GEN, int(c["k"], 16))
+        p1.append(p); p2.append(q)
+    assert PT.g1_compress(PT.g1_aggregate(p1)).hex() == v["sum_g1"]
+    assert PT.g2_compress(PT.g2_aggregate(p2)).hex() == v["sum_g2"]
+    for e in v["on_curve_outside_subgroup_g1"]:
+        assert PT.g1_decompress(bytes.fromhex(e))[0] == PT.NOT_IN_SUBGROUP
