@@ -1,6 +1,8 @@
 #include "witness.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "bls381_constants.h"
@@ -333,6 +335,15 @@ WitnessProgram build_program() {
             for (uint32_t i : rows) P.ops[phase].push_back(WitnessOp{i | ((uint32_t)w.kinds[i] << 28), w.ra[i], w.rb[i]});
             P.level_start[phase].push_back((uint32_t)P.ops[phase].size());
         }
+        if (getenv("BLS381_WIT_STATS")) {  // dependency-level widths
+            size_t hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (auto& rows : by) {
+                size_t wd = rows.size();
+                hist[wd <= 4 ? 0 : wd <= 8 ? 1 : wd <= 16 ? 2 : wd <= 32 ? 3 : wd <= 64 ? 4 : wd <= 128 ? 5 : wd <= 256 ? 6 : 7]++;
+            }
+            fprintf(stderr, "witness phase %d: %zu rows in %zu levels; widths <=4:%zu <=8:%zu <=16:%zu <=32:%zu <=64:%zu <=128:%zu <=256:%zu more:%zu\n",
+                    phase, hi - lo, by.size(), hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
+        }
     }
     return P;
 }
@@ -501,7 +512,15 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         WCHK(hipMemcpy(d_inv_refs_, P.inv_input_refs, 48, hipMemcpyHostToDevice));
         uploaded_ = true;
     }
-    const size_t CH = 512;  // proofs per pass (one workgroup each: two per CU): 512 x 6.8 MB of trace
+    // One wave per proof: dependency levels are about 35 rows wide, so a wider workgroup mostly idles at
+    // its barriers, and the kernel hides its load latency only by the number of proofs in flight
+    // (measured: 256 lanes x 512 proofs per pass 29 k proofs/s, 64 lanes x 4,096 91 k, x 16,384 104 k).
+    // The staging buffer of the host-pointer form (6.8 MB per proof) keeps that form to 1,024 per pass;
+    // its copy back to the host is what bounds it anyway.
+    size_t CH = on_device ? 16384 : 1024;
+    int block = 64;
+    if (const char* e = getenv("BLS381_WIT_CH")) CH = (size_t)atol(e);
+    if (const char* e = getenv("BLS381_WIT_BLOCK")) block = atoi(e);
     for (size_t off = 0; off < n; off += CH) {
         int m = (int)std::min(CH, n - off);
         size_t tbytes = (size_t)m * P.n_rows * 48;
@@ -517,7 +536,7 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         WCHK(hipMemcpyAsync(d_g2, g2 + off * 24, (size_t)m * 192, in_kind, stream));
         hipLaunchKernelGGL(witness_inputs_kernel, dim3((m * 6 + 63) / 64), dim3(64), 0, stream, d_g1, d_g2, (u32*)d_inputs_, m);
         WCHK(hipGetLastError());
-        hipLaunchKernelGGL(witness_kernel, dim3(m), dim3(256), 0, stream, d_ops_[0], d_levels_[0],
+        hipLaunchKernelGGL(witness_kernel, dim3(m), dim3(block), 0, stream, d_ops_[0], d_levels_[0],
                            (int)P.level_start[0].size() - 1, d_trace_m, P.n_rows, d_consts_, (const u32*)d_inputs_);
         WCHK(hipGetLastError());
         u32* d_x = (u32*)d_x_;
@@ -530,7 +549,7 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         hipLaunchKernelGGL(witness_scatter_kernel, dim3((m * 12 + 63) / 64), dim3(64), 0, stream, d_trace_m, P.n_rows,
                            P.gen_start, d_inv, m);
         WCHK(hipGetLastError());
-        hipLaunchKernelGGL(witness_kernel, dim3(m), dim3(256), 0, stream, d_ops_[1], d_levels_[1],
+        hipLaunchKernelGGL(witness_kernel, dim3(m), dim3(block), 0, stream, d_ops_[1], d_levels_[1],
                            (int)P.level_start[1].size() - 1, d_trace_m, P.n_rows, d_consts_, (const u32*)d_inputs_);
         WCHK(hipGetLastError());
         if (!on_device) WCHK(hipMemcpyAsync(trace + off * P.n_rows * 12, d_trace_, tbytes, hipMemcpyDeviceToHost, stream));
