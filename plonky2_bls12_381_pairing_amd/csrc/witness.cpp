@@ -370,16 +370,21 @@ __device__ __forceinline__ void w_load(const u32* base, u32 ref, const u32* T, c
     x[8] = c.x; x[9] = c.y; x[10] = c.z; x[11] = c.w;
 }
 
+// lpp lanes per proof: a workgroup of blockDim.x lanes serves blockDim.x / lpp proofs side by side
 __global__ __launch_bounds__(256) void witness_kernel(const WitnessOp* ops, const u32* level_start, int nlevels,
-                                                      u32* trace, size_t rows, const u32* consts, const u32* inputs) {
-    u32* T = trace + (size_t)blockIdx.x * rows * 12;
-    const u32* in = inputs + (size_t)blockIdx.x * 6 * 12;
+                                                      u32* trace, size_t rows, const u32* consts, const u32* inputs,
+                                                      int lpp, int nproofs) {
+    const int proof = blockIdx.x * (blockDim.x / lpp) + threadIdx.x / lpp;
+    const int sub = threadIdx.x % lpp;
+    const bool live = proof < nproofs;
+    u32* T = trace + (size_t)(live ? proof : 0) * rows * 12;
+    const u32* in = inputs + (size_t)(live ? proof : 0) * 6 * 12;
     const u32 P[12] = BLS381_P_LIMBS;
     const u32 R2[12] = {0x1c341746u, 0xf4df1f34u, 0x09d104f1u, 0x0a76e6a6u, 0x4c95b6d5u, 0x8de5476cu,
                         0x939d83c0u, 0x67eb88a9u, 0xb519952du, 0x9a793e85u, 0x92cae3aau, 0x11988fe5u};
     for (int l = 0; l < nlevels; l++) {
         const u32 lo = level_start[l], hi = level_start[l + 1];
-        for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        for (u32 i = lo + sub; live && i < hi; i += lpp) {
             const WitnessOp op = ops[i];
             const u32 kind = op.dst >> 28, row = op.dst & 0x0fffffffu;
             u32 a[12], b[12], r[12];
@@ -512,15 +517,19 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         WCHK(hipMemcpy(d_inv_refs_, P.inv_input_refs, 48, hipMemcpyHostToDevice));
         uploaded_ = true;
     }
-    // One wave per proof: dependency levels are about 35 rows wide, so a wider workgroup mostly idles at
-    // its barriers, and the kernel hides its load latency only by the number of proofs in flight
-    // (measured: 256 lanes x 512 proofs per pass 29 k proofs/s, 64 lanes x 4,096 91 k, x 16,384 104 k).
+    // Sixteen lanes per proof, four proofs per one-wave workgroup: dependency levels are about 35 rows wide
+    // (a third of them at most 16), so wider groups mostly idle at their barriers, and the kernel hides its load
+    // latency only by the number of proofs in flight (measured, proofs/s: 256 lanes per proof x 512 proofs per
+    // pass 29 k; 64 lanes x 16,384 104 k; 32 lanes 145 k; 16 lanes 167 k; 8 lanes 162 k).
     // The staging buffer of the host-pointer form (6.8 MB per proof) keeps that form to 1,024 per pass;
     // its copy back to the host is what bounds it anyway.
     size_t CH = on_device ? 16384 : 1024;
-    int block = 64;
+    int block = 64, lpp = 16;
     if (const char* e = getenv("BLS381_WIT_CH")) CH = (size_t)atol(e);
     if (const char* e = getenv("BLS381_WIT_BLOCK")) block = atoi(e);
+    if (const char* e = getenv("BLS381_WIT_LPP")) lpp = atoi(e);
+    if (lpp < 1 || lpp > block || block % lpp) { err = "BLS381_WIT_LPP must divide BLS381_WIT_BLOCK"; return -1; }
+    const int per_block = block / lpp;
     for (size_t off = 0; off < n; off += CH) {
         int m = (int)std::min(CH, n - off);
         size_t tbytes = (size_t)m * P.n_rows * 48;
@@ -536,8 +545,8 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         WCHK(hipMemcpyAsync(d_g2, g2 + off * 24, (size_t)m * 192, in_kind, stream));
         hipLaunchKernelGGL(witness_inputs_kernel, dim3((m * 6 + 63) / 64), dim3(64), 0, stream, d_g1, d_g2, (u32*)d_inputs_, m);
         WCHK(hipGetLastError());
-        hipLaunchKernelGGL(witness_kernel, dim3(m), dim3(block), 0, stream, d_ops_[0], d_levels_[0],
-                           (int)P.level_start[0].size() - 1, d_trace_m, P.n_rows, d_consts_, (const u32*)d_inputs_);
+        hipLaunchKernelGGL(witness_kernel, dim3((m + per_block - 1) / per_block), dim3(block), 0, stream, d_ops_[0], d_levels_[0],
+                           (int)P.level_start[0].size() - 1, d_trace_m, P.n_rows, d_consts_, (const u32*)d_inputs_, lpp, m);
         WCHK(hipGetLastError());
         u32* d_x = (u32*)d_x_;
         u32* d_inv = d_x + (size_t)m * 144;
@@ -549,8 +558,8 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         hipLaunchKernelGGL(witness_scatter_kernel, dim3((m * 12 + 63) / 64), dim3(64), 0, stream, d_trace_m, P.n_rows,
                            P.gen_start, d_inv, m);
         WCHK(hipGetLastError());
-        hipLaunchKernelGGL(witness_kernel, dim3(m), dim3(block), 0, stream, d_ops_[1], d_levels_[1],
-                           (int)P.level_start[1].size() - 1, d_trace_m, P.n_rows, d_consts_, (const u32*)d_inputs_);
+        hipLaunchKernelGGL(witness_kernel, dim3((m + per_block - 1) / per_block), dim3(block), 0, stream, d_ops_[1], d_levels_[1],
+                           (int)P.level_start[1].size() - 1, d_trace_m, P.n_rows, d_consts_, (const u32*)d_inputs_, lpp, m);
         WCHK(hipGetLastError());
         if (!on_device) WCHK(hipMemcpyAsync(trace + off * P.n_rows * 12, d_trace_, tbytes, hipMemcpyDeviceToHost, stream));
         WCHK(hipStreamSynchronize(stream));
