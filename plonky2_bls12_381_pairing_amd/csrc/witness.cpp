@@ -380,8 +380,6 @@ __global__ __launch_bounds__(256) void witness_kernel(const WitnessOp* ops, cons
     u32* T = trace + (size_t)(live ? proof : 0) * rows * 12;
     const u32* in = inputs + (size_t)(live ? proof : 0) * 6 * 12;
     const u32 P[12] = BLS381_P_LIMBS;
-    const u32 R2[12] = {0x1c341746u, 0xf4df1f34u, 0x09d104f1u, 0x0a76e6a6u, 0x4c95b6d5u, 0x8de5476cu,
-                        0x939d83c0u, 0x67eb88a9u, 0xb519952du, 0x9a793e85u, 0x92cae3aau, 0x11988fe5u};
     for (int l = 0; l < nlevels; l++) {
         const u32 lo = level_start[l], hi = level_start[l + 1];
         for (u32 i = lo + sub; live && i < hi; i += lpp) {
@@ -397,9 +395,7 @@ __global__ __launch_bounds__(256) void witness_kernel(const WitnessOp* ops, cons
                 r[8] = v2.x; r[9] = v2.y; r[10] = v2.z; r[11] = v2.w;
             } else if (kind == WK_MUL) {
                 w_load(T, op.b, T, consts, in, b);
-                u32 t[12];
-                fp_mul(a, b, t);   // a b / R
-                fp_mul(t, R2, r);  // * R^2 / R = a b
+                fp_mul_canon(a, b, r);  // rows are canonical values: no Montgomery factor to carry
             } else if (kind == WK_ADD) {
                 w_load(T, op.b, T, consts, in, b);
                 carry_t c;
@@ -520,7 +516,8 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
     // Sixteen lanes per proof, four proofs per one-wave workgroup: dependency levels are about 35 rows wide
     // (a third of them at most 16), so wider groups mostly idle at their barriers, and the kernel hides its load
     // latency only by the number of proofs in flight (measured, proofs/s: 256 lanes per proof x 512 proofs per
-    // pass 29 k; 64 lanes x 16,384 104 k; 32 lanes 145 k; 16 lanes 167 k; 8 lanes 162 k).
+    // pass 29 k; 64 lanes x 16,384 104 k; 32 lanes 145 k; 16 lanes 167 k; 8 lanes 162 k; with the Barrett
+    // product in place of two Montgomery products 190 k at 16 lanes).
     // The staging buffer of the host-pointer form (6.8 MB per proof) keeps that form to 1,024 per pass;
     // its copy back to the host is what bounds it anyway.
     size_t CH = on_device ? 16384 : 1024;
