@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbls381_hip.so")
+LIB_PATH = os.environ.get("BLS381_LIB_PATH") or os.path.join(_HERE, "libbls381_hip.so")  # (the override: A/B builds)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
