@@ -207,6 +207,16 @@ int bls381_g1_aggregate_batch(bls381_ctx*, const uint64_t* g1, const uint8_t* in
 int bls381_g2_aggregate_batch(bls381_ctx*, const uint64_t* g2, const uint8_t* inf, size_t n_groups, size_t group_size,
                               uint64_t* out, uint8_t* out_inf);
 
+/* n signature checks from bytes (minimal-public-key-size BLS: keys in G1, signatures and message points in
+ * G2), the whole chain on the device: decode the three encodings as above, reject a key at infinity, then
+ * native_pairing(&[pk, -G1::generator()], &[msg, sig]) == Fq12::ONE (/root/reference/src/native/pairing.rs:8-13)
+ * through the two-pair call.  msg96 is the compressed hash-to-curve output of the message (hashing itself is not
+ * done here).  verdict: one byte per item, 1 = the signature verifies.  status (may be NULL): 3 bytes per item,
+ * the BLS381_POINT_* status of key, message point and signature.  Malformed input is a verdict of 0, not an
+ * error return. */
+int bls381_verify_batch(bls381_ctx*, const uint8_t* pk48, const uint8_t* msg96, const uint8_t* sig96, size_t n,
+                        int check_subgroup, uint8_t* verdict, uint8_t* status);
+
 /* ---- one G2 point against many G1 points ------------------------------------------------------
  * G2Prepared (/root/reference/src/native/miller_loop.rs:13-16, 90-119) holds the 68 line coefficients
  * of Q so that they are computed once and reused by every Miller loop against that Q (:139-156).

@@ -122,6 +122,7 @@ struct bls381_ctx {
     unsigned long long* d_prof = nullptr;  // set while bls381_debug_profile runs
     const uint4* consts_override = nullptr;  // set while a program runs against a prepared G2 point's table
     DevBuf user_in, user_in2, user_in3, user_in4, user_out, flags, bufA, bufB, bufC, bufD, bufE, bufTmp, zflags;
+    DevBuf vbuf[8];  // stages of the signature check from bytes
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float last_ms[4] = {0, 0, 0, 0};  // Miller kernel, fe1 + inversion, fe2 kernel, whole device call
     std::mutex mu;
@@ -247,6 +248,7 @@ extern "C" void bls381_ctx_destroy(bls381_ctx* c) {
     for (DevBuf* b : {&c->user_in, &c->user_in2, &c->user_in3, &c->user_in4, &c->user_out, &c->flags, &c->bufA, &c->bufB,
                       &c->bufC, &c->bufD, &c->bufE, &c->bufTmp, &c->zflags})
         b->release();
+    for (auto& b : c->vbuf) b.release();
     c->wit.release();
     if (c->d_consts) (void)hipFree(c->d_consts);
     if (c->d_vmconsts) (void)hipFree(c->d_vmconsts);
@@ -1348,6 +1350,58 @@ extern "C" int bls381_g2_aggregate_batch(bls381_ctx* c, const uint64_t* g2, cons
                                          size_t group_size, uint64_t* out, uint8_t* out_inf) {
     CTX_GUARD(c);
     return aggregate_host<gen::F2>(c, g2, inf, n_groups, group_size, out, out_inf);
+}
+
+// n signature checks from bytes: pk 48 bytes (G1), message point 96 bytes (G2, the hash-to-curve output), signature
+// 96 bytes (G2).  verdict[i] = 1 iff all three decode (subgroup-checked when asked), pk is not infinity and
+// e(pk, msg) * e(-G1, sig) = 1.  status (optional): 3 bytes per item, the decoders' statuses of pk, msg, sig.
+extern "C" int bls381_verify_batch(bls381_ctx* c, const uint8_t* pk48, const uint8_t* msg96, const uint8_t* sig96, size_t n,
+                                   int check_subgroup, uint8_t* verdict, uint8_t* status) {
+    CTX_GUARD(c);
+    if (n == 0) return 0;
+    if (!pk48 || !msg96 || !sig96 || !verdict) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    if (n > MAX_POINTS) return fail(BLS381_ERR_INVALID, "at most 2^22 items per call");
+    enum { B_BYTES = 0, B_G1A, B_G2A, B_G2B, B_G1B, B_STATUS, B_FLAGS, B_ONE };
+    DevBuf* v = c->vbuf;
+    HIPCHK(v[B_BYTES].ensure(n * 96));
+    HIPCHK(v[B_G1A].ensure(n * 96));
+    HIPCHK(v[B_G2A].ensure(n * 192));
+    HIPCHK(v[B_G2B].ensure(n * 192));
+    HIPCHK(v[B_G1B].ensure(n * 96));
+    HIPCHK(v[B_STATUS].ensure(n * 3));
+    HIPCHK(v[B_FLAGS].ensure(n * 2));
+    HIPCHK(v[B_ONE].ensure(n * 2));
+    uint8_t* st = (uint8_t*)v[B_STATUS].p;
+    const int m = (int)n;
+    const dim3 grid((m + 63) / 64), block(64);
+    HIPCHK(hipMemcpyAsync(v[B_BYTES].p, pk48, n * 48, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pts::g1_decompress_kernel, grid, block, 0, c->stream, (const uint8_t*)v[B_BYTES].p, m, check_subgroup,
+                       (u32*)v[B_G1A].p, st);
+    HIPCHK(hipMemcpyAsync(v[B_BYTES].p, msg96, n * 96, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pts::g2_decompress_kernel, grid, block, 0, c->stream, (const uint8_t*)v[B_BYTES].p, m, check_subgroup,
+                       (u32*)v[B_G2A].p, st + n);
+    HIPCHK(hipMemcpyAsync(v[B_BYTES].p, sig96, n * 96, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pts::g2_decompress_kernel, grid, block, 0, c->stream, (const uint8_t*)v[B_BYTES].p, m, check_subgroup,
+                       (u32*)v[B_G2B].p, st + 2 * n);
+    hipLaunchKernelGGL(pts::fill_neg_g1_generator, grid, block, 0, c->stream, (u32*)v[B_G1B].p, m);
+    uint8_t* flags = (uint8_t*)v[B_FLAGS].p;
+    uint8_t* valid = flags + n;
+    hipLaunchKernelGGL(pts::verify_flags_kernel, grid, block, 0, c->stream, st, st + n, st + 2 * n, m, flags, valid);
+    HIPCHK(hipGetLastError());
+    uint8_t* is_one = (uint8_t*)v[B_ONE].p;
+    int rc = two_pairs_dev_locked(c, (const uint64_t*)v[B_G1A].p, (const uint64_t*)v[B_G2A].p, (const uint64_t*)v[B_G1B].p,
+                                  (const uint64_t*)v[B_G2B].p, flags, n, nullptr, is_one, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pts::verify_verdict_kernel, grid, block, 0, c->stream, is_one, valid, m, is_one + n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(verdict, is_one + n, n, hipMemcpyDeviceToHost));
+    if (status) {  // item-major for the caller
+        std::vector<uint8_t> s(3 * n);
+        HIPCHK(hipMemcpy(s.data(), st, 3 * n, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) { status[3 * i] = s[i]; status[3 * i + 1] = s[n + i]; status[3 * i + 2] = s[2 * n + i]; }
+    }
+    return 0;
 }
 
 // sustained v_mad_u64_u32 rate: 8 independent accumulators per lane, 8 waves per SIMD

@@ -312,5 +312,31 @@ __global__ __launch_bounds__(64) void agg_finish_kernel(const u32* in, int n_gro
     out_inf[g] = inf ? 1 : 0;
 }
 
+// ---- signature checks from bytes: glue between the decoders and the two-pair pairing
+// -G1 (the negated standard generator) for every item, Montgomery limbs
+__global__ void fill_neg_g1_generator(u32* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 X[12] = {0xfd530c16u, 0x5cb38790u, 0x9976fff5u, 0x7817fc67u, 0x143ba1c1u, 0x154f95c7u,
+                       0xf3d0e747u, 0xf0ae6acdu, 0x21dbf440u, 0xedce6eccu, 0x9e0bfb75u, 0x12017741u};
+    const u32 Y[12] = {0xf318883au, 0xff526c2au, 0x383b0270u, 0x92899ce4u, 0x9fa9d055u, 0x89d7738du,
+                       0xa344c12au, 0x12caf35bu, 0x964b5317u, 0x3cff1b76u, 0xe9774430u, 0x0e44d2edu};
+    for (int k = 0; k < 12; k++) { out[(size_t)i * 24 + k] = X[k]; out[(size_t)i * 24 + 12 + k] = Y[k]; }
+}
+// Decoder statuses of (public key, message point, signature) -> pairing flags and a validity byte.  A key at
+// infinity is rejected (KeyValidate); a message point or signature at infinity leaves its pair out of the product.
+__global__ void verify_flags_kernel(const uint8_t* st_pk, const uint8_t* st_msg, const uint8_t* st_sig, int n,
+                                    uint8_t* pair_flags, uint8_t* valid) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool ok = st_pk[i] == ST_OK && st_msg[i] <= ST_INFINITY && st_sig[i] <= ST_INFINITY;
+    valid[i] = ok ? 1 : 0;
+    pair_flags[i] = !ok ? 15 : (uint8_t)((st_msg[i] == ST_INFINITY ? 2 : 0) | (st_sig[i] == ST_INFINITY ? 8 : 0));
+}
+__global__ void verify_verdict_kernel(const uint8_t* is_one, const uint8_t* valid, int n, uint8_t* verdict) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) verdict[i] = (is_one[i] && valid[i]) ? 1 : 0;
+}
+
 }  // namespace pts
 }  // namespace bls381

@@ -356,6 +356,20 @@ class Context:
     def g2_aggregate_batch(self, g2, group_size, inf=None):
         return self._aggregate(lib.bls381_g2_aggregate_batch, g2, 24, group_size, inf)
 
+    def verify_batch(self, pk, msg, sig, check_subgroup=True):
+        """Signature checks from bytes: (n, 48) keys, (n, 96) message points, (n, 96) signatures ->
+        ((n,) verdicts, (n, 3) decoder statuses)."""
+        pk = np.ascontiguousarray(pk, dtype=np.uint8)
+        msg = np.ascontiguousarray(msg, dtype=np.uint8)
+        sig = np.ascontiguousarray(sig, dtype=np.uint8)
+        n = pk.shape[0]
+        if pk.shape != (n, 48) or msg.shape != (n, 96) or sig.shape != (n, 96):
+            raise ValueError("expected shapes (n, 48), (n, 96), (n, 96)")
+        verdict = np.zeros(n, dtype=np.uint8)
+        status = np.zeros((n, 3), dtype=np.uint8)
+        check(lib.bls381_verify_batch(self._h, _p8(pk), _p8(msg), _p8(sig), n, 1 if check_subgroup else 0, _p8(verdict), _p8(status)))
+        return verdict, status
+
     def pairing_witness_batch(self, g1, g2):
         g1, g2 = _arr64(g1, 12), _arr64(g2, 24)
         n = g1.shape[0]

@@ -604,3 +604,49 @@ def test_point_format_golden_vectors(ctx):
     assert ctx.g2_compress_batch(s2, i2).tobytes().hex() == v["sum_g2"]
     _, st = ctx.g1_decompress_batch(_bytes_array([bytes.fromhex(e) for e in v["on_curve_outside_subgroup_g1"]]), return_status=True)
     assert st.tolist() == [4, 4]
+
+
+def test_signature_checks_from_bytes(ctx):
+    """bls381_verify_batch against the oracle: decode with oracle/py/bls381_points.py, then
+    native_pairing([pk, -G1], [msg, sig]) == 1 with the big-integer pairing."""
+    import random
+    import bls381_points as PT
+    rng = random.Random(4242)
+    pks, msgs, sigs = [], [], []
+    for i in range(4):
+        sk, h = rng.randrange(1, R.R_ORDER), rng.randrange(1, R.R_ORDER)
+        hm = R.g2_mul(R.G2_GEN, h)
+        pks.append(PT.g1_compress(R.g1_mul(R.G1_GEN, sk)))
+        msgs.append(PT.g2_compress(hm))
+        sigs.append(PT.g2_compress(R.g2_mul(hm, sk if i != 1 else sk + 1)))      # item 1: wrong signature
+    # item 4: key at infinity with signature at infinity (the product is one, the key is still rejected)
+    pks.append(PT.g1_compress(None)); msgs.append(msgs[0]); sigs.append(PT.g2_compress(None))
+    # item 5: signature at infinity under a real key
+    pks.append(pks[0]); msgs.append(msgs[0]); sigs.append(PT.g2_compress(None))
+    # item 6: malformed key (x = p); item 7: key on the curve but outside the subgroup
+    tb = bytearray(R.P.to_bytes(48, "big")); tb[0] |= 0x80
+    pks.append(bytes(tb)); msgs.append(msgs[2]); sigs.append(sigs[2])
+    x = 4
+    while R.fq_sqrt((x ** 3 + 4) % R.P) is None:
+        x += 1
+    e = bytearray(x.to_bytes(48, "big")); e[0] |= 0x80
+    pks.append(bytes(e)); msgs.append(msgs[2]); sigs.append(sigs[2])
+    # item 8: a valid triple again, after the rejects
+    pks.append(pks[3]); msgs.append(msgs[3]); sigs.append(sigs[3])
+    verdict, status = ctx.verify_batch(_bytes_array(pks), _bytes_array(msgs), _bytes_array(sigs))
+    want_v, want_s = [], []
+    neg_g1 = R.g1_neg(R.G1_GEN)
+    for pk, m, s in zip(pks, msgs, sigs):
+        (s1, p), (s2, hm), (s3, sg) = PT.g1_decompress(pk), PT.g2_decompress(m), PT.g2_decompress(s)
+        want_s.append([s1, s2, s3])
+        if s1 != PT.OK or s2 > PT.INFINITY or s3 > PT.INFINITY:
+            want_v.append(0)
+            continue
+        pairs = [(p, hm), (neg_g1, sg)]
+        pairs = [(a, b) for a, b in pairs if a is not None and b is not None]
+        want_v.append(1 if R.native_pairing([a for a, _ in pairs], [b for _, b in pairs]) == R.FQ12_ONE else 0)
+    assert status.tolist() == want_s
+    assert verdict.tolist() == want_v == [1, 0, 1, 1, 0, 0, 0, 0, 1]
+    # without the subgroup test the off-subgroup key decodes, and its check fails in the pairing instead
+    v2, s2 = ctx.verify_batch(_bytes_array(pks), _bytes_array(msgs), _bytes_array(sigs), check_subgroup=False)
+    assert s2[7].tolist() == [0, 0, 0] and v2.tolist() == want_v

@@ -38,3 +38,18 @@ for n in (65536,):
     timed("G1 aggregate, 128 groups of 512 keys", lambda: ctx.g1_aggregate_batch(p1, 512), n)
     timed("G1 aggregate, 1 group of 512 keys", lambda: ctx.g1_aggregate_batch(p1[:512], 512), 512)
     timed("G2 aggregate, 128 groups of 512 signatures", lambda: ctx.g2_aggregate_batch(p2, 512), n)
+
+# signature checks from bytes: 64 distinct (key, message point, signature) triples tiled
+import random
+rng = random.Random(7)
+pk, mg, sg = [], [], []
+for _ in range(64):
+    sk, h = rng.randrange(1, R.R_ORDER), rng.randrange(1, R.R_ORDER)
+    hm = R.g2_mul(R.G2_GEN, h)
+    pk.append(PT.g1_compress(R.g1_mul(R.G1_GEN, sk))); mg.append(PT.g2_compress(hm)); sg.append(PT.g2_compress(R.g2_mul(hm, sk)))
+tile = lambda enc, w: np.tile(np.frombuffer(b"".join(enc), dtype=np.uint8).reshape(64, w), (65536 // 64, 1))
+bpk, bmg, bsg = tile(pk, 48), tile(mg, 96), tile(sg, 96)
+for chk in (True, False):
+    v, _ = ctx.verify_batch(bpk, bmg, bsg, check_subgroup=chk)
+    assert v.all()
+    timed("signature checks from bytes, subgroup tests %s" % ("on" if chk else "off"), lambda: ctx.verify_batch(bpk, bmg, bsg, check_subgroup=chk), 65536)
