@@ -192,10 +192,13 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
     // or reduction there spares each consumer (and their consumers) its own.
     auto env_int = [](const char* nm, int dflt) { const char* v = getenv(nm); return v ? atoi(v) : dflt; };
     const int VB_EAGER = env_int("BLS381_VB_EAGER", 400), DB_EAGER = env_int("BLS381_DB_EAGER", 3);
-    for (bool again = true; again;) {
-        again = false;
-        for (int i = 0; i < n && !again; i++) {
+    // One pass in node order; when node i asks for a treatment of an operand x, everything from x on is
+    // recomputed (nothing before x depends on x's flags).
+    {
+        for (int i = 0; i < n;) {
             const Node& nd = N[i];
+            int redo = -1;  // node whose flags changed
+            auto treated = [&](int x, std::vector<char>& flag, int& counter) { treat(x, flag, counter); redo = x; };
             switch (nd.kind) {
                 case NK_LOADIN: vb[i] = 10; db[i] = 1; break;  // any 384-bit pattern is below 10p
                 case NK_LOADC: vb[i] = 1; db[i] = 1; break;
@@ -208,8 +211,8 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                         ops.push_back(nd.c); ops.push_back(nd.d);
                         sv += (long)vb[nd.c] * vb[nd.d]; sd += db[nd.c] * db[nd.d];
                     }
-                    if (sv > (narrow[i] ? 2500L : MUL_VB_LIMIT)) { treat(widest(ops, vb, lin_reduce), lin_reduce, n_reduce); again = true; }
-                    else if (sd > MUL_DB_LIMIT) { treat(widest(ops, db, lin_norm), lin_norm, n_norm); again = true; }
+                    if (sv > (narrow[i] ? 2500L : MUL_VB_LIMIT)) treated(widest(ops, vb, lin_reduce), lin_reduce, n_reduce);
+                    else if (sd > MUL_DB_LIMIT) treated(widest(ops, db, lin_norm), lin_norm, n_norm);
                     vb[i] = 1 + (int)((sv + 2519) / 2520); db[i] = 1;
                     break;
                 }
@@ -217,8 +220,8 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                     int sv = 0, sd = 0;
                     std::vector<int> ops;
                     for (auto& t : nd.terms) { sv += vb[t.node]; sd += db[t.node]; ops.push_back(t.node); }
-                    if (sv > SUM_VB_LIMIT) { treat(widest(ops, vb, lin_reduce), lin_reduce, n_reduce); again = true; }
-                    else if (sd > SUM_DB_LIMIT) { treat(widest(ops, db, lin_norm), lin_norm, n_norm); again = true; }
+                    if (sv > SUM_VB_LIMIT) treated(widest(ops, vb, lin_reduce), lin_reduce, n_reduce);
+                    else if (sd > SUM_DB_LIMIT) treated(widest(ops, db, lin_norm), lin_norm, n_norm);
                     else if (succ[i].size() >= 2) {
                         if (sv >= VB_EAGER && !lin_reduce[i]) { lin_reduce[i] = 1; n_reduce++; }
                         else if (sd >= DB_EAGER && !lin_norm[i] && !lin_reduce[i]) { lin_norm[i] = 1; n_norm++; }
@@ -231,9 +234,10 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                     // a store handles (-p, 2p) with normalised digits: what multiplications produce
                     if (N[nd.a].kind != NK_FMUL && N[nd.a].kind != NK_DOT2)
                         throw std::runtime_error("scheduler: stored value must come from a multiplication");
-                    if (vb[nd.a] > 2 && !narrow[nd.a]) { narrow[nd.a] = 1; again = true; }
+                    if (vb[nd.a] > 2 && !narrow[nd.a]) { narrow[nd.a] = 1; redo = nd.a; }
                     break;
             }
+            i = redo >= 0 ? redo : i + 1;
         }
     }
     n_norm = 0;
