@@ -650,3 +650,41 @@ def test_signature_checks_from_bytes(ctx):
     # without the subgroup test the off-subgroup key decodes, and its check fails in the pairing instead
     v2, s2 = ctx.verify_batch(_bytes_array(pks), _bytes_array(msgs), _bytes_array(sigs), check_subgroup=False)
     assert s2[7].tolist() == [0, 0, 0] and v2.tolist() == want_v
+
+
+def test_new_entry_points_edge_sizes(ctx, CO):
+    """Empty inputs, and a two-pair batch that spans two chunks with infinity flags in the second one."""
+    import bls381_points as PT
+    z8 = np.zeros((0, 48), dtype=np.uint8)
+    out, st = ctx.g1_decompress_batch(z8)
+    assert out.shape == (0, 12) and st.shape == (0,)
+    assert ctx.g2_compress_batch(np.zeros((0, 24), dtype=np.uint64)).shape == (0, 96)
+    agg, inf = ctx.g1_aggregate_batch(np.zeros((0, 12), dtype=np.uint64), 4)
+    assert agg.shape == (0, 12) and inf.shape == (0,)
+    v, s = ctx.verify_batch(z8, np.zeros((0, 96), dtype=np.uint8), np.zeros((0, 96), dtype=np.uint8))
+    assert v.shape == (0,) and s.shape == (0, 3)
+    e = np.zeros((0, 12), dtype=np.uint64); f = np.zeros((0, 24), dtype=np.uint64)
+    o, one = ctx.pairing_two_pairs_batch(e, f, e, f)
+    assert o.shape == (0, 72) and one.shape == (0,)
+    with pytest.raises(ValueError):
+        ctx.g1_aggregate_batch(np.zeros((5, 12), dtype=np.uint64), 4)      # not a whole number of groups
+
+    n = 65536 + 70
+    ps, qs = H.random_pairs(5, 808)
+    g1 = np.tile(H.g1_array(ps), (n // 5 + 1, 1))[:n]; g2 = np.tile(H.g2_array(qs), (n // 5 + 1, 1))[:n]
+    h1 = np.roll(g1, 1, 0); h2 = np.roll(g2, 2, 0)
+    flags = np.zeros(n, dtype=np.uint8)
+    flags[65536 + 3] = 1          # first pair skipped
+    flags[65536 + 11] = 4         # second pair skipped
+    flags[65536 + 20] = 2 | 8     # both skipped
+    flags[17] = 8
+    got, is_one = ctx.pairing_two_pairs_batch(g1, g2, h1, h2, inf_flags=flags)
+    idx = np.array([0, 17, 65535, 65536, 65536 + 3, 65536 + 11, 65536 + 20, n - 1])
+    ma, mb = CO.pairing_batch(g1[idx], g2[idx], final_exp=False), CO.pairing_batch(h1[idx], h2[idx], final_exp=False)
+    one = H.fq12_array([R.FQ12_ONE])[0]
+    for k, i in enumerate(idx):
+        if flags[i] & 3: ma[k] = one
+        if flags[i] & 12: mb[k] = one
+    want = ctx.final_exponentiation_batch(ctx.fq12_mul_batch(ma, mb))
+    assert np.array_equal(got[idx], want)
+    assert is_one[65536 + 20] == 1 and is_one.sum() == 1
