@@ -2,7 +2,7 @@
  *
  * The reference (a Rust crate) has no FFI of its own; its boundary is the public Rust API of
  * src/native/.  Each entry point below names the Rust item it replaces.  A Rust caller keeps the
- * reference's signatures and forwards to these functions (binding sketch: INTEGRATION.md).
+ * reference's signatures and forwards to these functions.
  *
  * Data layouts (all little-endian):
  *   Fq    6 x u64, Montgomery form with R = 2^384: the in-memory limbs of ark_ff's Fq

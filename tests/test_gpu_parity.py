@@ -207,7 +207,7 @@ def test_fq12_inverse_generator_limbs(ctx):
 
 
 def test_full_batch_65536_against_c_oracle_and_bilinearity(ctx, CO):
-    """BASELINE config 2: 65,536 independent pairings, every output compared with the CPU oracle
+    """The full-size case: 65,536 independent pairings, every output compared with the CPU oracle
     on the distinct inputs, plus size-independent properties on the whole batch."""
     n = 65536
     base = 64
