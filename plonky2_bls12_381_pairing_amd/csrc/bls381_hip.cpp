@@ -135,9 +135,13 @@ struct bls381_ctx {
 // lanes) and the final exponentiation (22.7 vs 24.3 ms), so every program uses the context's K.
 // The two-pair Miller loop is the exception: with twice the independent work per item it fills 16
 // lanes (17.4 ms against 18.5 ms at 8), and is run that way when the context uses the defaults.
+// Small batches are another: below half a round of the GPU (8,192 lane groups of 8) latency is all that counts,
+// and 16 lanes per item shorten every program (one pairing 4.4 -> 3.0 ms, the 513-pair aggregate check 4.7 ->
+// 3.2 ms).  Those variants carry the suffix "@16" and are scheduled on first use.
+static std::string base_name(const std::string& which) { return which.substr(0, which.find('@')); }
 static void program_geometry(const bls381_ctx* c, const std::string& which, int& K, int& slots) {
     K = c->K; slots = c->lds_slots;
-    if (c->auto_geometry && which == "miller2") { K = 16; slots = default_slots(16); }
+    if (c->auto_geometry && (which == "miller2" || which.find("@16") != std::string::npos)) { K = 16; slots = default_slots(16); }
 }
 
 // Synthetic programs for timing one step kind in isolation: 1,000 identical steps with every lane
@@ -186,7 +190,7 @@ static int upload_program(bls381_ctx* c, const std::string& which) {
         int K, slots;
         program_geometry(c, which, K, slots);
         if (which.rfind("t_", 0) == 0) dp.host = microbench_program(which, K, slots);
-        else dp.host = schedule(build_named(which), K, slots, which);
+        else dp.host = schedule(build_named(base_name(which)), K, slots, which);
     } catch (std::exception& e) {
         return fail(BLS381_ERR_INVALID, std::string("program ") + which + ": " + e.what());
     }
@@ -287,12 +291,22 @@ template <int K>
 static hipError_t launch_vm_k(bls381_ctx* c, const DevProgram& p, const uint4* gin, uint4* gout, uint4* gtmp, int n,
                               int npad) {
     if (c->d_prof) return launch_vm_kt<K, TAG_PROFILE>(c, p, gin, gout, gtmp, n, npad);
-    if (p.host.name == "miller" || p.host.name == "millerfq") return launch_vm_kt<K, TAG_MILLER>(c, p, gin, gout, gtmp, n, npad);
-    if (p.host.name == "fe2") return launch_vm_kt<K, TAG_FINAL_EXP>(c, p, gin, gout, gtmp, n, npad);
+    const std::string base = base_name(p.host.name);
+    if (base == "miller" || base == "millerfq") return launch_vm_kt<K, TAG_MILLER>(c, p, gin, gout, gtmp, n, npad);
+    if (base == "fe2") return launch_vm_kt<K, TAG_FINAL_EXP>(c, p, gin, gout, gtmp, n, npad);
     return launch_vm_kt<K, TAG_AUX>(c, p, gin, gout, gtmp, n, npad);
 }
 
-static int run_program(bls381_ctx* c, const char* which, const void* gin, void* gout, int n, int npad) {
+enum { SMALL_BATCH = 8192 };
+static int run_program(bls381_ctx* c, const char* which_c, const void* gin, void* gout, int n, int npad) {
+    std::string which = which_c;
+    if (c->auto_geometry && n <= SMALL_BATCH && which != "miller2" && which.rfind("t_", 0) != 0) {
+        which += "@16";
+        if (!c->progs.count(which)) {
+            int rc = upload_program(c, which);
+            if (rc) return rc;
+        }
+    }
     auto it = c->progs.find(which);
     if (it == c->progs.end()) return fail(BLS381_ERR_INVALID, std::string("no program ") + which);
     const DevProgram& p = it->second;

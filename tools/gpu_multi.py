@@ -7,8 +7,9 @@ import numpy as np
 import helpers as H
 import plonky2_bls12_381_pairing_amd as B
 ps, qs = H.random_pairs(16, 5)
-ctx = B.Context(0)
-for n in (1, 16, 513, 4096, 65536):
+geo = [int(x) for x in os.environ.get('GEO', '0:0').split(':')]
+ctx = B.Context(0, geo[0], geo[1])
+for n in (1, 16, 513, 4096, 16384):
     reps = (n + 15) // 16
     g1 = np.tile(H.g1_array(ps), (reps, 1))[:n]; g2 = np.tile(H.g2_array(qs), (reps, 1))[:n]
     ctx.native_pairing(g1, g2)
