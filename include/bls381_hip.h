@@ -213,9 +213,12 @@ int bls381_g2_aggregate_batch(bls381_ctx*, const uint64_t* g2, const uint8_t* in
  * through the two-pair call.  msg96 is the compressed hash-to-curve output of the message (hashing itself is not
  * done here).  verdict: one byte per item, 1 = the signature verifies.  status (may be NULL): 3 bytes per item,
  * the BLS381_POINT_* status of key, message point and signature.  Malformed input is a verdict of 0, not an
- * error return. */
+ * error return.  check_subgroup_mask says which of the three inputs get the order-r membership test: keys and
+ * signatures come from outside; message points a caller has hashed itself are in the subgroup by construction
+ * and can skip it (BLS381_CHECK_KEYS | BLS381_CHECK_SIGNATURES). */
+enum { BLS381_CHECK_KEYS = 1, BLS381_CHECK_MESSAGES = 2, BLS381_CHECK_SIGNATURES = 4 };
 int bls381_verify_batch(bls381_ctx*, const uint8_t* pk48, const uint8_t* msg96, const uint8_t* sig96, size_t n,
-                        int check_subgroup, uint8_t* verdict, uint8_t* status);
+                        int check_subgroup_mask, uint8_t* verdict, uint8_t* status);
 
 /* ---- one G2 point against many G1 points ------------------------------------------------------
  * G2Prepared (/root/reference/src/native/miller_loop.rs:13-16, 90-119) holds the 68 line coefficients

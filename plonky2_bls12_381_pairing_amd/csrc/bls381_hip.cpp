@@ -1367,7 +1367,7 @@ extern "C" int bls381_g2_aggregate_batch(bls381_ctx* c, const uint64_t* g2, cons
 }
 
 // n signature checks from bytes: pk 48 bytes (G1), message point 96 bytes (G2, the hash-to-curve output), signature
-// 96 bytes (G2).  verdict[i] = 1 iff all three decode (subgroup-checked when asked), pk is not infinity and
+// 96 bytes (G2).  verdict[i] = 1 iff all three decode (subgroup-checked as the mask asks), pk is not infinity and
 // e(pk, msg) * e(-G1, sig) = 1.  status (optional): 3 bytes per item, the decoders' statuses of pk, msg, sig.
 extern "C" int bls381_verify_batch(bls381_ctx* c, const uint8_t* pk48, const uint8_t* msg96, const uint8_t* sig96, size_t n,
                                    int check_subgroup, uint8_t* verdict, uint8_t* status) {
@@ -1389,14 +1389,14 @@ extern "C" int bls381_verify_batch(bls381_ctx* c, const uint8_t* pk48, const uin
     const int m = (int)n;
     const dim3 grid((m + 63) / 64), block(64);
     HIPCHK(hipMemcpyAsync(v[B_BYTES].p, pk48, n * 48, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(pts::g1_decompress_kernel, grid, block, 0, c->stream, (const uint8_t*)v[B_BYTES].p, m, check_subgroup,
-                       (u32*)v[B_G1A].p, st);
+    hipLaunchKernelGGL(pts::g1_decompress_kernel, grid, block, 0, c->stream, (const uint8_t*)v[B_BYTES].p, m,
+                       (check_subgroup & BLS381_CHECK_KEYS) ? 1 : 0, (u32*)v[B_G1A].p, st);
     HIPCHK(hipMemcpyAsync(v[B_BYTES].p, msg96, n * 96, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(pts::g2_decompress_kernel, grid, block, 0, c->stream, (const uint8_t*)v[B_BYTES].p, m, check_subgroup,
-                       (u32*)v[B_G2A].p, st + n);
+    hipLaunchKernelGGL(pts::g2_decompress_kernel, grid, block, 0, c->stream, (const uint8_t*)v[B_BYTES].p, m,
+                       (check_subgroup & BLS381_CHECK_MESSAGES) ? 1 : 0, (u32*)v[B_G2A].p, st + n);
     HIPCHK(hipMemcpyAsync(v[B_BYTES].p, sig96, n * 96, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(pts::g2_decompress_kernel, grid, block, 0, c->stream, (const uint8_t*)v[B_BYTES].p, m, check_subgroup,
-                       (u32*)v[B_G2B].p, st + 2 * n);
+    hipLaunchKernelGGL(pts::g2_decompress_kernel, grid, block, 0, c->stream, (const uint8_t*)v[B_BYTES].p, m,
+                       (check_subgroup & BLS381_CHECK_SIGNATURES) ? 1 : 0, (u32*)v[B_G2B].p, st + 2 * n);
     hipLaunchKernelGGL(pts::fill_neg_g1_generator, grid, block, 0, c->stream, (u32*)v[B_G1B].p, m);
     uint8_t* flags = (uint8_t*)v[B_FLAGS].p;
     uint8_t* valid = flags + n;

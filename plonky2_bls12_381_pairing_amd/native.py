@@ -65,6 +65,9 @@ class G2Prepared:
             pass
 
 
+CHECK_KEYS, CHECK_MESSAGES, CHECK_SIGNATURES = 1, 2, 4
+
+
 class Context:
     """One GPU.  lanes_per_group / lds_slots = 0 select the defaults."""
 
@@ -358,7 +361,12 @@ class Context:
 
     def verify_batch(self, pk, msg, sig, check_subgroup=True):
         """Signature checks from bytes: (n, 48) keys, (n, 96) message points, (n, 96) signatures ->
-        ((n,) verdicts, (n, 3) decoder statuses)."""
+        ((n,) verdicts, (n, 3) decoder statuses).  check_subgroup: True (all three inputs), False (none) or a
+        mask of CHECK_KEYS | CHECK_MESSAGES | CHECK_SIGNATURES."""
+        if check_subgroup is True:
+            check_subgroup = 7
+        elif check_subgroup is False:
+            check_subgroup = 0
         pk = np.ascontiguousarray(pk, dtype=np.uint8)
         msg = np.ascontiguousarray(msg, dtype=np.uint8)
         sig = np.ascontiguousarray(sig, dtype=np.uint8)
@@ -367,7 +375,7 @@ class Context:
             raise ValueError("expected shapes (n, 48), (n, 96), (n, 96)")
         verdict = np.zeros(n, dtype=np.uint8)
         status = np.zeros((n, 3), dtype=np.uint8)
-        check(lib.bls381_verify_batch(self._h, _p8(pk), _p8(msg), _p8(sig), n, 1 if check_subgroup else 0, _p8(verdict), _p8(status)))
+        check(lib.bls381_verify_batch(self._h, _p8(pk), _p8(msg), _p8(sig), n, int(check_subgroup), _p8(verdict), _p8(status)))
         return verdict, status
 
     def pairing_witness_batch(self, g1, g2):
