@@ -688,3 +688,20 @@ def test_new_entry_points_edge_sizes(ctx, CO):
     want = ctx.final_exponentiation_batch(ctx.fq12_mul_batch(ma, mb))
     assert np.array_equal(got[idx], want)
     assert is_one[65536 + 20] == 1 and is_one.sum() == 1
+
+
+def test_one_gpu_shard_of_the_8m_configuration(ctx, CO):
+    """1,048,576 pairs (what one of 8 GPUs gets of 8,388,608) through the host-pointer call: a strided sample
+    against the CPU oracle, and the periodicity of the synthetic input as a whole-output property."""
+    n, period = 1 << 20, 4096
+    ps, qs = H.random_pairs(64, 3003)
+    a, b = H.g1_array(ps), H.g2_array(qs)
+    i = np.arange(period)
+    g1p, g2p = a[i % 64], b[(i // 64) % 64]                 # 4,096 distinct pairs
+    g1, g2 = np.tile(g1p, (n // period, 1)), np.tile(g2p, (n // period, 1))
+    out = ctx.pairing_batch(g1, g2)
+    sample = np.arange(0, n, n // 128) + 5                    # 1/8192 of the outputs, every chunk touched
+    assert np.array_equal(out[sample], CO.pairing_batch(g1[sample], g2[sample]))
+    first = out[:period]
+    assert np.array_equal(out.reshape(n // period, period, 72), np.broadcast_to(first, (n // period, period, 72)))
+    assert np.array_equal(first[:64], CO.pairing_batch(g1p[:64], g2p[:64]))
