@@ -277,11 +277,12 @@ static hipError_t launch_vm_kt(bls381_ctx* c, const DevProgram& p, const uint4* 
     // the spill array's 8-byte tails follow its 48-byte parts
     a.gtmp_tail = reinterpret_cast<uint2*>(gtmp + (size_t)std::max(1, p.host.n_tmp_slots) * 3 * npad);
     size_t lds = vm_lds_bytes(p.host.n_lds_slots, K);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};  // per device: a process may hold contexts on several GPUs
+    const int dev = c->device & 63;
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)vm_kernel<K, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     int blocks = (n + GPW - 1) / GPW;
     hipLaunchKernelGGL((vm_kernel<K, TAG>), dim3(blocks), dim3(VM_THREADS), lds, c->stream, a);
