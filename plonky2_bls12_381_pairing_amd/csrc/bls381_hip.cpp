@@ -115,6 +115,7 @@ struct bls381_ctx {
     bool auto_geometry = false;  // defaults requested: per-program lane-group width
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;       // host copies of the pipelined host-pointer calls
+    hipStream_t aux_stream = nullptr;        // third stream: the three decoders of a signature check run side by side
     std::vector<hipEvent_t> pipe_ev;         // their per-slice events
     std::map<std::string, DevProgram> progs;
     uint4* d_consts = nullptr;
@@ -225,7 +226,8 @@ extern "C" int bls381_ctx_create_ex(bls381_ctx** out, int device_id, int K, int 
     c->device = device_id; c->K = K; c->lds_slots = lds_slots; c->auto_geometry = auto_geometry;
     int rc = 0;
     auto bail = [&](int code) { bls381_ctx_destroy(c); return code; };
-    if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->copy_stream) != hipSuccess)
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->copy_stream) != hipSuccess ||
+        hipStreamCreate(&c->aux_stream) != hipSuccess)
         return bail(fail(BLS381_ERR_HIP, "hipStreamCreate failed"));
     for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) return bail(fail(BLS381_ERR_HIP, "hipEventCreate failed"));
     std::vector<uint32_t> consts, vmc;
@@ -259,6 +261,7 @@ extern "C" void bls381_ctx_destroy(bls381_ctx* c) {
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->pipe_ev) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1378,7 +1381,7 @@ extern "C" int bls381_verify_batch(bls381_ctx* c, const uint8_t* pk48, const uin
     if (n > MAX_POINTS) return fail(BLS381_ERR_INVALID, "at most 2^22 items per call");
     enum { B_BYTES = 0, B_G1A, B_G2A, B_G2B, B_G1B, B_STATUS, B_FLAGS, B_ONE };
     DevBuf* v = c->vbuf;
-    HIPCHK(v[B_BYTES].ensure(n * 96));
+    HIPCHK(v[B_BYTES].ensure(n * 240));
     HIPCHK(v[B_G1A].ensure(n * 96));
     HIPCHK(v[B_G2A].ensure(n * 192));
     HIPCHK(v[B_G2B].ensure(n * 192));
@@ -1386,18 +1389,30 @@ extern "C" int bls381_verify_batch(bls381_ctx* c, const uint8_t* pk48, const uin
     HIPCHK(v[B_STATUS].ensure(n * 3));
     HIPCHK(v[B_FLAGS].ensure(n * 2));
     HIPCHK(v[B_ONE].ensure(n * 2));
+    while (c->pipe_ev.size() < 2) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->pipe_ev.push_back(e);
+    }
     uint8_t* st = (uint8_t*)v[B_STATUS].p;
     const int m = (int)n;
     const dim3 grid((m + 63) / 64), block(64);
-    HIPCHK(hipMemcpyAsync(v[B_BYTES].p, pk48, n * 48, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(pts::g1_decompress_kernel, grid, block, 0, c->stream, (const uint8_t*)v[B_BYTES].p, m,
+    // The decoders run one lane per point: a batch of 65,536 is a single wave per SIMD, so the three of them go
+    // on three streams and share the GPU.
+    uint8_t* bytes = (uint8_t*)v[B_BYTES].p;
+    HIPCHK(hipMemcpyAsync(bytes, pk48, n * 48, hipMemcpyHostToDevice, c->copy_stream));
+    hipLaunchKernelGGL(pts::g1_decompress_kernel, grid, block, 0, c->copy_stream, (const uint8_t*)bytes, m,
                        (check_subgroup & BLS381_CHECK_KEYS) ? 1 : 0, (u32*)v[B_G1A].p, st);
-    HIPCHK(hipMemcpyAsync(v[B_BYTES].p, msg96, n * 96, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(pts::g2_decompress_kernel, grid, block, 0, c->stream, (const uint8_t*)v[B_BYTES].p, m,
+    HIPCHK(hipEventRecord(c->pipe_ev[0], c->copy_stream));
+    HIPCHK(hipMemcpyAsync(bytes + n * 48, msg96, n * 96, hipMemcpyHostToDevice, c->aux_stream));
+    hipLaunchKernelGGL(pts::g2_decompress_kernel, grid, block, 0, c->aux_stream, (const uint8_t*)bytes + n * 48, m,
                        (check_subgroup & BLS381_CHECK_MESSAGES) ? 1 : 0, (u32*)v[B_G2A].p, st + n);
-    HIPCHK(hipMemcpyAsync(v[B_BYTES].p, sig96, n * 96, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(pts::g2_decompress_kernel, grid, block, 0, c->stream, (const uint8_t*)v[B_BYTES].p, m,
+    HIPCHK(hipEventRecord(c->pipe_ev[1], c->aux_stream));
+    HIPCHK(hipMemcpyAsync(bytes + n * 144, sig96, n * 96, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pts::g2_decompress_kernel, grid, block, 0, c->stream, (const uint8_t*)bytes + n * 144, m,
                        (check_subgroup & BLS381_CHECK_SIGNATURES) ? 1 : 0, (u32*)v[B_G2B].p, st + 2 * n);
+    HIPCHK(hipStreamWaitEvent(c->stream, c->pipe_ev[0], 0));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->pipe_ev[1], 0));
     hipLaunchKernelGGL(pts::fill_neg_g1_generator, grid, block, 0, c->stream, (u32*)v[B_G1B].p, m);
     uint8_t* flags = (uint8_t*)v[B_FLAGS].p;
     uint8_t* valid = flags + n;
