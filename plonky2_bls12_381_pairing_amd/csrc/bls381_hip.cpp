@@ -115,6 +115,7 @@ struct bls381_ctx {
     bool auto_geometry = false;  // defaults requested: per-program lane-group width
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;       // host copies of the pipelined host-pointer calls
+    bool no_sync = false;                    // set by the pipelined host calls: device-pointer bodies only enqueue
     hipStream_t aux_stream = nullptr;        // third stream: the three decoders of a signature check run side by side
     std::vector<hipEvent_t> pipe_ev;         // their per-slice events
     std::map<std::string, DevProgram> progs;
@@ -404,6 +405,7 @@ static int miller_dev_locked(bls381_ctx* c, const uint64_t* g1, const uint64_t* 
                                     with_final_exp);
         if (rc) return rc;
     }
+    if (c->no_sync) return 0;
     HIPCHK(hipStreamSynchronize(c->stream));
     if (n) {  // timings of the last chunk
         (void)hipEventElapsedTime(&c->last_ms[0], c->ev[1], c->ev[2]);
@@ -465,6 +467,7 @@ static int two_pairs_dev_locked(bls381_ctx* c, const uint64_t* g1a, const uint64
         if (out && (rc = unpack(c, c->bufB.p, out + off * 72, m, npad, 12, 0))) return rc;
         HIPCHK(hipEventRecord(c->ev[5], c->stream));
     }
+    if (c->no_sync) return 0;
     HIPCHK(hipStreamSynchronize(c->stream));
     if (n) {
         (void)hipEventElapsedTime(&c->last_ms[0], c->ev[1], c->ev[2]);
@@ -609,6 +612,7 @@ static int fixed_q_dev_locked(bls381_ctx* c, const bls381_g2_prepared* q, const 
         if (rc) return rc;
         HIPCHK(hipEventRecord(c->ev[5], c->stream));
     }
+    if (c->no_sync) return 0;
     HIPCHK(hipStreamSynchronize(c->stream));
     if (n) {
         (void)hipEventElapsedTime(&c->last_ms[0], c->ev[1], c->ev[2]);
@@ -683,51 +687,40 @@ static int h2d(bls381_ctx* c, DevBuf& b, const void* src, size_t bytes) {
     return 0;
 }
 
-// Host-pointer form, pipelined: the batch is cut into slices of one or more full rounds of the GPU (16,384 pairs:
+// Host-pointer forms, pipelined: the batch is cut into slices of one or more full rounds of the GPU (16,384 items:
 // 64 lane groups on each of 256 CUs); while slice k computes on the context's stream, the copy stream brings
 // slice k + 1 in and takes slice k - 1 out.  Host memory is the caller's (pageable): each copy blocks the calling
 // thread, which is why a slice's kernels are enqueued before the next copy is started.
-static int pairs_host(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags, size_t n,
-                      uint64_t* out, bool fe) {
-    if (n && (!g1 || !g2 || !out)) return fail(BLS381_ERR_INVALID, "NULL buffer");
-    if (n == 0) return 0;
+// copy_in(off, m) and copy_out(off, m) enqueue on the copy stream, run(off, m) on the context's stream.
+template <class In, class Run, class Out>
+static int pipelined_host(bls381_ctx* c, size_t n, In copy_in, Run run, Out copy_out) {
     // (measured, ms per 65,536 pairs: one chunk 27.8 with 16,384-pair slices, 30.9 unsliced; four chunks 26.8 / 25.8 /
     // 25.5 with slices of 16,384 / 32,768 / 65,536: short slices pay the small kernels' launch latency more often)
     size_t SLICE = n >= 4 * (size_t)CHUNK ? (size_t)CHUNK : (n > (size_t)CHUNK ? 32768 : 16384);
     if (const char* e = getenv("BLS381_SLICE")) SLICE = (size_t)std::max(64L, std::min((long)CHUNK, atol(e) / 64 * 64));
     const size_t nslices = (n + SLICE - 1) / SLICE;
-    HIPCHK(c->user_in.ensure(n * 96));
-    HIPCHK(c->user_in2.ensure(n * 192));
-    if (flags) HIPCHK(c->flags.ensure(n));
-    HIPCHK(c->user_out.ensure(n * 576));
     while (c->pipe_ev.size() < 2 * nslices) {
         hipEvent_t e;
         HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->pipe_ev.push_back(e);
     }
     auto slice_len = [&](size_t k) { return std::min(SLICE, n - k * SLICE); };
-    auto copy_out = [&](size_t k) -> int {
+    auto take_out = [&](size_t k) -> int {
         HIPCHK(hipStreamWaitEvent(c->copy_stream, c->pipe_ev[2 * k + 1], 0));
-        HIPCHK(hipMemcpyAsync(out + k * SLICE * 72, (const char*)c->user_out.p + k * SLICE * 576, slice_len(k) * 576,
-                              hipMemcpyDeviceToHost, c->copy_stream));
-        return 0;
+        return copy_out(k * SLICE, slice_len(k));
     };
+    struct Guard { bls381_ctx* c; ~Guard() { c->no_sync = false; } } guard{c};
+    c->no_sync = true;
     int rc;
     for (size_t k = 0; k < nslices; k++) {
-        const size_t off = k * SLICE, m = slice_len(k);
-        HIPCHK(hipMemcpyAsync((char*)c->user_in.p + off * 96, g1 + off * 12, m * 96, hipMemcpyHostToDevice, c->copy_stream));
-        HIPCHK(hipMemcpyAsync((char*)c->user_in2.p + off * 192, g2 + off * 24, m * 192, hipMemcpyHostToDevice, c->copy_stream));
-        if (flags) HIPCHK(hipMemcpyAsync((char*)c->flags.p + off, flags + off, m, hipMemcpyHostToDevice, c->copy_stream));
+        if ((rc = copy_in(k * SLICE, slice_len(k)))) return rc;
         HIPCHK(hipEventRecord(c->pipe_ev[2 * k], c->copy_stream));
         HIPCHK(hipStreamWaitEvent(c->stream, c->pipe_ev[2 * k], 0));
-        rc = miller_dev_enqueue(c, (const uint64_t*)c->user_in.p + off * 12, (const uint64_t*)c->user_in2.p + off * 24,
-                                flags ? (const uint8_t*)c->flags.p + off : nullptr, (int)m,
-                                (uint64_t*)c->user_out.p + off * 72, fe);
-        if (rc) return rc;
+        if ((rc = run(k * SLICE, slice_len(k)))) return rc;
         HIPCHK(hipEventRecord(c->pipe_ev[2 * k + 1], c->stream));
-        if (k > 0 && (rc = copy_out(k - 1))) return rc;
+        if (k > 0 && (rc = take_out(k - 1))) return rc;
     }
-    if ((rc = copy_out(nslices - 1))) return rc;
+    if ((rc = take_out(nslices - 1))) return rc;
     HIPCHK(hipStreamSynchronize(c->copy_stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     (void)hipEventElapsedTime(&c->last_ms[0], c->ev[1], c->ev[2]);  // the last slice
@@ -736,6 +729,36 @@ static int pairs_host(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, con
     (void)hipEventElapsedTime(&c->last_ms[3], c->ev[0], c->ev[5]);
     return 0;
 }
+#define H2D_SLICE(buf, src, elem_bytes) \
+    HIPCHK(hipMemcpyAsync((char*)(buf).p + off * (elem_bytes), (const char*)(src) + off * (elem_bytes), m * (elem_bytes), hipMemcpyHostToDevice, c->copy_stream))
+#define D2H_SLICE(dst, buf, elem_bytes) \
+    HIPCHK(hipMemcpyAsync((char*)(dst) + off * (elem_bytes), (const char*)(buf).p + off * (elem_bytes), m * (elem_bytes), hipMemcpyDeviceToHost, c->copy_stream))
+
+static int pairs_host(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags, size_t n,
+                      uint64_t* out, bool fe) {
+    if (n && (!g1 || !g2 || !out)) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    if (n == 0) return 0;
+    HIPCHK(c->user_in.ensure(n * 96));
+    HIPCHK(c->user_in2.ensure(n * 192));
+    if (flags) HIPCHK(c->flags.ensure(n));
+    HIPCHK(c->user_out.ensure(n * 576));
+    return pipelined_host(
+        c, n,
+        [&](size_t off, size_t m) -> int {
+            H2D_SLICE(c->user_in, g1, 96);
+            H2D_SLICE(c->user_in2, g2, 192);
+            if (flags) H2D_SLICE(c->flags, flags, 1);
+            return 0;
+        },
+        [&](size_t off, size_t m) -> int {
+            return miller_dev_locked(c, (const uint64_t*)c->user_in.p + off * 12, (const uint64_t*)c->user_in2.p + off * 24,
+                                     flags ? (const uint8_t*)c->flags.p + off : nullptr, m, (uint64_t*)c->user_out.p + off * 72, fe);
+        },
+        [&](size_t off, size_t m) -> int {
+            D2H_SLICE(out, c->user_out, 576);
+            return 0;
+        });
+}
 
 static int fixed_q_host(bls381_ctx* c, const bls381_g2_prepared* q, const uint64_t* g1, const uint8_t* flags, size_t n,
                         uint64_t* out, bool fe) {
@@ -743,18 +766,25 @@ static int fixed_q_host(bls381_ctx* c, const bls381_g2_prepared* q, const uint64
     if (q->device != c->device) return fail(BLS381_ERR_INVALID, "prepared point belongs to another device");
     if (n && (!g1 || !out)) return fail(BLS381_ERR_INVALID, "NULL buffer");
     if (n == 0) return 0;
-    int rc;
-    if ((rc = h2d(c, c->user_in, g1, n * 96))) return rc;
-    const uint8_t* fdev = nullptr;
-    if (flags) {
-        if ((rc = h2d(c, c->flags, flags, n))) return rc;
-        fdev = (const uint8_t*)c->flags.p;
-    }
+    HIPCHK(c->user_in.ensure(n * 96));
+    if (flags) HIPCHK(c->user_in2.ensure(n));  // (fixed_q_dev_locked uses c->flags itself when Q is infinity)
     HIPCHK(c->user_out.ensure(n * 576));
-    rc = fixed_q_dev_locked(c, q, (const uint64_t*)c->user_in.p, fdev, n, (uint64_t*)c->user_out.p, fe);
-    if (rc) return rc;
-    HIPCHK(hipMemcpy(out, c->user_out.p, n * 576, hipMemcpyDeviceToHost));
-    return 0;
+    return pipelined_host(
+        c, n,
+        [&](size_t off, size_t m) -> int {
+            H2D_SLICE(c->user_in, g1, 96);
+            if (flags) H2D_SLICE(c->user_in2, flags, 1);
+            return 0;
+        },
+        [&](size_t off, size_t m) -> int {
+            return fixed_q_dev_locked(c, q, (const uint64_t*)c->user_in.p + off * 12,
+                                      flags ? (const uint8_t*)c->user_in2.p + off : nullptr, m,
+                                      (uint64_t*)c->user_out.p + off * 72, fe);
+        },
+        [&](size_t off, size_t m) -> int {
+            D2H_SLICE(out, c->user_out, 576);
+            return 0;
+        });
 }
 extern "C" int bls381_miller_loop_fixed_q_batch(bls381_ctx* c, const bls381_g2_prepared* q, const uint64_t* g1,
                                                 const uint8_t* p_is_infinity, size_t n, uint64_t* out) {
@@ -790,25 +820,35 @@ static int two_pairs_host(bls381_ctx* c, const uint64_t* g1a, const uint64_t* g2
                           const uint8_t* flags, size_t n, uint64_t* out, uint8_t* is_one, bool fe) {
     if (n && (!g1a || !g2a || !g1b || !g2b || (!out && !is_one))) return fail(BLS381_ERR_INVALID, "NULL buffer");
     if (n == 0) return 0;
-    int rc;
-    if ((rc = h2d(c, c->user_in, g1a, n * 96))) return rc;
-    if ((rc = h2d(c, c->user_in2, g2a, n * 192))) return rc;
-    if ((rc = h2d(c, c->user_in3, g1b, n * 96))) return rc;
-    if ((rc = h2d(c, c->user_in4, g2b, n * 192))) return rc;
-    const uint8_t* fdev = nullptr;
-    if (flags) {
-        if ((rc = h2d(c, c->flags, flags, n))) return rc;
-        fdev = (const uint8_t*)c->flags.p;
-    }
+    HIPCHK(c->user_in.ensure(n * 96));
+    HIPCHK(c->user_in2.ensure(n * 192));
+    HIPCHK(c->user_in3.ensure(n * 96));
+    HIPCHK(c->user_in4.ensure(n * 192));
+    if (flags) HIPCHK(c->flags.ensure(n));
     if (out) HIPCHK(c->user_out.ensure(n * 576));
     if (is_one) HIPCHK(c->zflags.ensure(n));
-    rc = two_pairs_dev_locked(c, (const uint64_t*)c->user_in.p, (const uint64_t*)c->user_in2.p, (const uint64_t*)c->user_in3.p,
-                              (const uint64_t*)c->user_in4.p, fdev, n, out ? (uint64_t*)c->user_out.p : nullptr,
-                              is_one ? (uint8_t*)c->zflags.p : nullptr, fe);
-    if (rc) return rc;
-    if (out) HIPCHK(hipMemcpy(out, c->user_out.p, n * 576, hipMemcpyDeviceToHost));
-    if (is_one) HIPCHK(hipMemcpy(is_one, c->zflags.p, n, hipMemcpyDeviceToHost));
-    return 0;
+    return pipelined_host(
+        c, n,
+        [&](size_t off, size_t m) -> int {
+            H2D_SLICE(c->user_in, g1a, 96);
+            H2D_SLICE(c->user_in2, g2a, 192);
+            H2D_SLICE(c->user_in3, g1b, 96);
+            H2D_SLICE(c->user_in4, g2b, 192);
+            if (flags) H2D_SLICE(c->flags, flags, 1);
+            return 0;
+        },
+        [&](size_t off, size_t m) -> int {
+            return two_pairs_dev_locked(c, (const uint64_t*)c->user_in.p + off * 12, (const uint64_t*)c->user_in2.p + off * 24,
+                                        (const uint64_t*)c->user_in3.p + off * 12, (const uint64_t*)c->user_in4.p + off * 24,
+                                        flags ? (const uint8_t*)c->flags.p + off : nullptr, m,
+                                        out ? (uint64_t*)c->user_out.p + off * 72 : nullptr,
+                                        is_one ? (uint8_t*)c->zflags.p + off : nullptr, fe);
+        },
+        [&](size_t off, size_t m) -> int {
+            if (out) D2H_SLICE(out, c->user_out, 576);
+            if (is_one) D2H_SLICE(is_one, c->zflags, 1);
+            return 0;
+        });
 }
 extern "C" int bls381_miller_loop_two_pairs_batch(bls381_ctx* c, const uint64_t* g1a, const uint64_t* g2a, const uint64_t* g1b,
                                                   const uint64_t* g2b, const uint8_t* flags, size_t n, uint64_t* out) {

@@ -18,3 +18,10 @@ for name, fn in (("fixed-Q pairing", lambda: ctx.pairing_fixed_q_batch(prep, g1)
         fn()
     dt = (time.perf_counter() - t0) / 3
     print("%s: %.2f ms per 65,536 (host pointers); device kernels: %s ms" % (name, dt * 1e3, ["%.2f" % x for x in ctx.last_timing()]))
+h1, h2 = np.roll(g1, 1, 0), np.roll(g2, 3, 0)
+fn = lambda: ctx.pairing_two_pairs_batch(g1, g2, h1, h2)
+fn()
+t0 = time.perf_counter()
+for _ in range(3):
+    fn()
+print("two pairs per item: %.2f ms per 65,536 items (host pointers)" % ((time.perf_counter() - t0) / 3 * 1e3))
