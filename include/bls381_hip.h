@@ -220,6 +220,13 @@ enum { BLS381_CHECK_KEYS = 1, BLS381_CHECK_MESSAGES = 2, BLS381_CHECK_SIGNATURES
 int bls381_verify_batch(bls381_ctx*, const uint8_t* pk48, const uint8_t* msg96, const uint8_t* sig96, size_t n,
                         int check_subgroup_mask, uint8_t* verdict, uint8_t* status);
 
+/* One signature by n_keys signers over one message (FastAggregateVerify; the 512-key sync-committee check): keys
+ * decoded and summed on the device, then native_pairing(&[sum, -G1::generator()], &[msg, sig]) == Fq12::ONE.
+ * *valid = 1 iff every key decodes to a finite point, message point and signature decode, and the product is
+ * one; key_status (may be NULL) receives the n_keys decoder statuses.  check_subgroup_mask as above. */
+int bls381_fast_aggregate_verify(bls381_ctx*, const uint8_t* pk48, size_t n_keys, const uint8_t* msg96,
+                                 const uint8_t* sig96, int check_subgroup_mask, int* valid, uint8_t* key_status);
+
 /* ---- one G2 point against many G1 points ------------------------------------------------------
  * G2Prepared (/root/reference/src/native/miller_loop.rs:13-16, 90-119) holds the 68 line coefficients
  * of Q so that they are computed once and reused by every Miller loop against that Q (:139-156).

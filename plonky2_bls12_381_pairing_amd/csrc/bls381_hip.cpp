@@ -1360,7 +1360,31 @@ extern "C" int bls381_g2_compress_batch(bls381_ctx* c, const uint64_t* g2, const
         hipLaunchKernelGGL(pts::g2_compress_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, d, f, m, o);
     });
 }
-// sums of n_groups groups of group_size points each
+// sums of n_groups groups of group_size points each; everything in device memory, enqueued on the context's stream
+template <class T>
+static int aggregate_dev(bls381_ctx* c, const u32* pts_dev, const uint8_t* inf_dev, size_t n_groups, size_t group_size,
+                         u32* out_dev, uint8_t* out_inf_dev) {
+    constexpr size_t FQ = pts::Width<T>::FQ;
+    size_t count = group_size, half = (count + 1) / 2;
+    HIPCHK(c->bufA.ensure(n_groups * half * 3 * FQ * 48));
+    HIPCHK(c->bufB.ensure(n_groups * ((half + 1) / 2) * 3 * FQ * 48));
+    u32 *cur = (u32*)c->bufA.p, *other = (u32*)c->bufB.p;
+    auto blocks = [](size_t threads) { return dim3((unsigned)((threads + 63) / 64)); };
+    hipLaunchKernelGGL(pts::agg_first_kernel<T>, blocks(n_groups * half), dim3(64), 0, c->stream, pts_dev, inf_dev,
+                       (int)n_groups, (int)count, (int)half, cur);
+    HIPCHK(hipGetLastError());
+    for (count = half; count > 1; count = half) {
+        half = (count + 1) / 2;
+        hipLaunchKernelGGL(pts::agg_pass_kernel<T>, blocks(n_groups * half), dim3(64), 0, c->stream, (const u32*)cur,
+                           (int)n_groups, (int)count, (int)half, other);
+        HIPCHK(hipGetLastError());
+        std::swap(cur, other);
+    }
+    hipLaunchKernelGGL(pts::agg_finish_kernel<T>, blocks(n_groups), dim3(64), 0, c->stream, (const u32*)cur, (int)n_groups,
+                       out_dev, out_inf_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 template <class T>
 static int aggregate_host(bls381_ctx* c, const uint64_t* pts_in, const uint8_t* inf, size_t n_groups, size_t group_size,
                           uint64_t* out, uint8_t* out_inf) {
@@ -1374,26 +1398,11 @@ static int aggregate_host(bls381_ctx* c, const uint64_t* pts_in, const uint8_t* 
     int rc;
     if ((rc = h2d(c, c->user_in, pts_in, n * 2 * FQ * 48))) return rc;
     if (inf && (rc = h2d(c, c->flags, inf, n))) return rc;
-    size_t count = group_size, half = (count + 1) / 2;
-    HIPCHK(c->bufA.ensure(n_groups * half * 3 * FQ * 48));
-    HIPCHK(c->bufB.ensure(n_groups * ((half + 1) / 2) * 3 * FQ * 48));
-    u32 *cur = (u32*)c->bufA.p, *other = (u32*)c->bufB.p;
-    auto blocks = [](size_t threads) { return dim3((unsigned)((threads + 63) / 64)); };
-    hipLaunchKernelGGL(pts::agg_first_kernel<T>, blocks(n_groups * half), dim3(64), 0, c->stream, (const u32*)c->user_in.p,
-                       inf ? (const uint8_t*)c->flags.p : nullptr, (int)n_groups, (int)count, (int)half, cur);
-    HIPCHK(hipGetLastError());
-    for (count = half; count > 1; count = half) {
-        half = (count + 1) / 2;
-        hipLaunchKernelGGL(pts::agg_pass_kernel<T>, blocks(n_groups * half), dim3(64), 0, c->stream, (const u32*)cur,
-                           (int)n_groups, (int)count, (int)half, other);
-        HIPCHK(hipGetLastError());
-        std::swap(cur, other);
-    }
     HIPCHK(c->user_out.ensure(n_groups * 2 * FQ * 48));
     HIPCHK(c->zflags.ensure(n_groups));
-    hipLaunchKernelGGL(pts::agg_finish_kernel<T>, blocks(n_groups), dim3(64), 0, c->stream, (const u32*)cur, (int)n_groups,
-                       (u32*)c->user_out.p, (uint8_t*)c->zflags.p);
-    HIPCHK(hipGetLastError());
+    if ((rc = aggregate_dev<T>(c, (const u32*)c->user_in.p, inf ? (const uint8_t*)c->flags.p : nullptr, n_groups, group_size,
+                               (u32*)c->user_out.p, (uint8_t*)c->zflags.p)))
+        return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, c->user_out.p, n_groups * 2 * FQ * 48, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out_inf, c->zflags.p, n_groups, hipMemcpyDeviceToHost));
@@ -1471,6 +1480,73 @@ extern "C" int bls381_verify_batch(bls381_ctx* c, const uint8_t* pk48, const uin
         HIPCHK(hipMemcpy(s.data(), st, 3 * n, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; i++) { status[3 * i] = s[i]; status[3 * i + 1] = s[n + i]; status[3 * i + 2] = s[2 * n + i]; }
     }
+    return 0;
+}
+
+// One signature over one message by n_keys signers (the sync-committee shape): keys decoded and summed on the device,
+// then e(sum, msg) * e(-G1, sig) == 1.  *valid = 1 iff every key decodes to a finite point (subgroup-checked when the
+// mask asks), message point and signature decode, and the product is one.
+extern "C" int bls381_fast_aggregate_verify(bls381_ctx* c, const uint8_t* pk48, size_t n_keys, const uint8_t* msg96,
+                                            const uint8_t* sig96, int check_subgroup, int* valid, uint8_t* key_status) {
+    CTX_GUARD(c);
+    if (!valid) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    *valid = 0;
+    if (n_keys == 0) return 0;  // no signers: nothing verifies
+    if (!pk48 || !msg96 || !sig96) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    if (n_keys > MAX_POINTS) return fail(BLS381_ERR_INVALID, "at most 2^22 keys per call");
+    enum { B_BYTES = 0, B_G1A, B_G2A, B_G2B, B_G1B, B_STATUS, B_FLAGS, B_ONE };
+    DevBuf* v = c->vbuf;
+    const size_t n = n_keys;
+    HIPCHK(v[B_BYTES].ensure(n * 48 + 192));
+    HIPCHK(v[B_G1A].ensure(n * 96 + 96));   // the keys, then their sum
+    HIPCHK(v[B_G2A].ensure(192));
+    HIPCHK(v[B_G2B].ensure(192));
+    HIPCHK(v[B_G1B].ensure(96));
+    HIPCHK(v[B_STATUS].ensure(n + 16));
+    HIPCHK(v[B_FLAGS].ensure(16));
+    HIPCHK(v[B_ONE].ensure(16));
+    while (c->pipe_ev.size() < 2) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->pipe_ev.push_back(e);
+    }
+    uint8_t* bytes = (uint8_t*)v[B_BYTES].p;
+    uint8_t* st = (uint8_t*)v[B_STATUS].p;  // [0, n) keys, n message point, n + 1 signature, n + 2 the sum's infinity flag
+    const int m = (int)n;
+    HIPCHK(hipMemcpyAsync(bytes + n * 48, msg96, 96, hipMemcpyHostToDevice, c->copy_stream));
+    hipLaunchKernelGGL(pts::g2_decompress_kernel, dim3(1), dim3(64), 0, c->copy_stream, (const uint8_t*)bytes + n * 48, 1,
+                       (check_subgroup & BLS381_CHECK_MESSAGES) ? 1 : 0, (u32*)v[B_G2A].p, st + n);
+    HIPCHK(hipEventRecord(c->pipe_ev[0], c->copy_stream));
+    HIPCHK(hipMemcpyAsync(bytes + n * 48 + 96, sig96, 96, hipMemcpyHostToDevice, c->aux_stream));
+    hipLaunchKernelGGL(pts::g2_decompress_kernel, dim3(1), dim3(64), 0, c->aux_stream, (const uint8_t*)bytes + n * 48 + 96, 1,
+                       (check_subgroup & BLS381_CHECK_SIGNATURES) ? 1 : 0, (u32*)v[B_G2B].p, st + n + 1);
+    HIPCHK(hipEventRecord(c->pipe_ev[1], c->aux_stream));
+    HIPCHK(hipMemcpyAsync(bytes, pk48, n * 48, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pts::g1_decompress_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, (const uint8_t*)bytes, m,
+                       (check_subgroup & BLS381_CHECK_KEYS) ? 1 : 0, (u32*)v[B_G1A].p, st);
+    HIPCHK(hipGetLastError());
+    u32* sum = (u32*)v[B_G1A].p + n * 24;
+    int rc = aggregate_dev<gen::F>(c, (const u32*)v[B_G1A].p, nullptr, 1, n, sum, st + n + 2);  // rejected keys are zero points:
+    if (rc) return rc;                                                                          // the verdict below ignores the sum then
+    hipLaunchKernelGGL(pts::fill_neg_g1_generator, dim3(1), dim3(64), 0, c->stream, (u32*)v[B_G1B].p, 1);
+    HIPCHK(hipStreamWaitEvent(c->stream, c->pipe_ev[0], 0));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->pipe_ev[1], 0));
+    std::vector<uint8_t> hs(n + 3);
+    HIPCHK(hipMemcpyAsync(hs.data(), st, n + 3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (key_status) std::memcpy(key_status, hs.data(), n);
+    for (size_t i = 0; i < n; i++)
+        if (hs[i] != BLS381_POINT_OK) return 0;  // a malformed, off-curve, off-subgroup or infinite key: not valid
+    if (hs[n] > BLS381_POINT_INFINITY || hs[n + 1] > BLS381_POINT_INFINITY) return 0;
+    const uint8_t flag = (uint8_t)((hs[n + 2] ? 1 : 0) | (hs[n] == BLS381_POINT_INFINITY ? 2 : 0) |
+                                   (hs[n + 1] == BLS381_POINT_INFINITY ? 8 : 0));
+    HIPCHK(hipMemcpyAsync(v[B_FLAGS].p, &flag, 1, hipMemcpyHostToDevice, c->stream));
+    rc = two_pairs_dev_locked(c, (const uint64_t*)sum, (const uint64_t*)v[B_G2A].p, (const uint64_t*)v[B_G1B].p,
+                              (const uint64_t*)v[B_G2B].p, (const uint8_t*)v[B_FLAGS].p, 1, nullptr, (uint8_t*)v[B_ONE].p, true);
+    if (rc) return rc;
+    uint8_t one = 0;
+    HIPCHK(hipMemcpy(&one, v[B_ONE].p, 1, hipMemcpyDeviceToHost));
+    *valid = one ? 1 : 0;
     return 0;
 }
 

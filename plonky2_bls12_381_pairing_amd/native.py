@@ -378,6 +378,24 @@ class Context:
         check(lib.bls381_verify_batch(self._h, _p8(pk), _p8(msg), _p8(sig), n, int(check_subgroup), _p8(verdict), _p8(status)))
         return verdict, status
 
+    def fast_aggregate_verify(self, pk, msg, sig, check_subgroup=True):
+        """One signature (96 bytes) by the (n, 48) keys over one message point (96 bytes) -> (valid, key statuses)."""
+        pk = np.ascontiguousarray(pk, dtype=np.uint8)
+        msg = np.ascontiguousarray(np.frombuffer(bytes(msg), dtype=np.uint8))
+        sig = np.ascontiguousarray(np.frombuffer(bytes(sig), dtype=np.uint8))
+        n = pk.shape[0]
+        if pk.shape != (n, 48) or msg.shape != (96,) or sig.shape != (96,):
+            raise ValueError("expected (n, 48) keys and 96-byte message point and signature")
+        if check_subgroup is True:
+            check_subgroup = 7
+        elif check_subgroup is False:
+            check_subgroup = 0
+        valid = _lib.C.c_int(0)
+        status = np.zeros(n, dtype=np.uint8)
+        check(lib.bls381_fast_aggregate_verify(self._h, _p8(pk), n, _p8(msg), _p8(sig), int(check_subgroup),
+                                               _lib.C.byref(valid), _p8(status)))
+        return bool(valid.value), status
+
     def pairing_witness_batch(self, g1, g2):
         g1, g2 = _arr64(g1, 12), _arr64(g2, 24)
         n = g1.shape[0]

@@ -705,3 +705,42 @@ def test_one_gpu_shard_of_the_8m_configuration(ctx, CO):
     first = out[:period]
     assert np.array_equal(out.reshape(n // period, period, 72), np.broadcast_to(first, (n // period, period, 72)))
     assert np.array_equal(first[:64], CO.pairing_batch(g1p[:64], g2p[:64]))
+
+
+def test_fast_aggregate_verify_from_bytes(ctx):
+    """512 signers, one message: keys decoded and summed on the device, then the two-pair check; against
+    signatures built with the oracle's group arithmetic."""
+    import random
+    import bls381_points as PT
+    rng = random.Random(512)
+    sks = [rng.randrange(1, R.R_ORDER) for _ in range(512)]
+    # 512 scalar multiplications in Python are slow: derive the keys from a short chain instead
+    base = R.g1_mul(R.G1_GEN, sks[0])
+    keys, ks, acc, k = [], [], base, sks[0]
+    step_k = rng.randrange(1, R.R_ORDER)
+    step = R.g1_mul(R.G1_GEN, step_k)
+    for _ in range(512):
+        keys.append(acc); ks.append(k)
+        acc = R.g1_add(acc, step); k = (k + step_k) % R.R_ORDER
+    hm = R.g2_mul(R.G2_GEN, rng.randrange(1, R.R_ORDER))
+    total = sum(ks) % R.R_ORDER
+    sig = R.g2_mul(hm, total)
+    pk = _bytes_array([PT.g1_compress(p) for p in keys])
+    msg, good, bad = PT.g2_compress(hm), PT.g2_compress(sig), PT.g2_compress(R.g2_mul(hm, total + 1))
+    valid, st = ctx.fast_aggregate_verify(pk, msg, good)
+    assert valid and not st.any()
+    assert not ctx.fast_aggregate_verify(pk, msg, bad)[0]
+    assert ctx.fast_aggregate_verify(pk, msg, good, check_subgroup=False)[0]
+    # a subset of 3 and of 1 signers
+    for cnt in (3, 1):
+        s = PT.g2_compress(R.g2_mul(hm, sum(ks[:cnt]) % R.R_ORDER))
+        assert ctx.fast_aggregate_verify(pk[:cnt], msg, s)[0]
+        assert not ctx.fast_aggregate_verify(pk[:cnt + 1], msg, s)[0]
+    # a key at infinity or a malformed key invalidates the whole check, and is reported
+    broken = pk.copy(); broken[7] = np.frombuffer(PT.g1_compress(None), dtype=np.uint8)
+    valid, st = ctx.fast_aggregate_verify(broken, msg, good)
+    assert not valid and st[7] == PT.INFINITY and st.sum() == 1
+    broken = pk.copy(); broken[100, 0] &= 0x7F
+    valid, st = ctx.fast_aggregate_verify(broken, msg, good)
+    assert not valid and st[100] == PT.BAD_ENCODING
+    assert ctx.fast_aggregate_verify(pk[:0], msg, good)[0] is False

@@ -53,3 +53,17 @@ for label, chk in (("all three inputs", 7), ("keys and signatures", 5), ("none",
     v, _ = ctx.verify_batch(bpk, bmg, bsg, check_subgroup=chk)
     assert v.all()
     timed("signature checks from bytes, subgroup tests: %s" % label, lambda: ctx.verify_batch(bpk, bmg, bsg, check_subgroup=chk), 65536)
+
+# one signature by 512 signers (keys from a chain, as in the test)
+keys, acc = [], R.g1_mul(R.G1_GEN, 12345)
+stepp = R.g1_mul(R.G1_GEN, 999331)
+tot = 0
+for i in range(512):
+    keys.append(PT.g1_compress(acc)); tot += 12345 + 999331 * i
+    acc = R.g1_add(acc, stepp)
+hm = R.g2_mul(R.G2_GEN, 424242)
+pk512 = np.frombuffer(b"".join(keys), dtype=np.uint8).reshape(512, 48)
+msgb, sigb = PT.g2_compress(hm), PT.g2_compress(R.g2_mul(hm, tot % R.R_ORDER))
+for label, chk in (("all inputs", 7), ("signature only", 4), ("none", 0)):
+    assert ctx.fast_aggregate_verify(pk512, msgb, sigb, check_subgroup=chk)[0]
+    timed("512-signer aggregate check from bytes, subgroup tests: %s" % label, lambda: ctx.fast_aggregate_verify(pk512, msgb, sigb, check_subgroup=chk), 512)
