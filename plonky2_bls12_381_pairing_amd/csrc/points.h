@@ -21,8 +21,14 @@ enum Status : uint8_t { ST_OK = 0, ST_INFINITY = 1, ST_BAD_ENCODING = 2, ST_NOT_
 
 // ---- field helpers, out of line: these kernels are long chains of products and code size matters
 __device__ __noinline__ F M(const F& a, const F& b) { return gen::mul(a, b); }
+// (a0 + a1 u)(b0 + b1 u): each component is a sum of two products with one reduction (fp_dot2), the minus sign of
+// a1 b1 goes into the operand
 __device__ __noinline__ F2 M(const F2& a, const F2& b) {
-    return {gen::sub(M(a.c0, b.c0), M(a.c1, b.c1)), gen::add(M(a.c0, b.c1), M(a.c1, b.c0))};
+    const F nb1 = gen::sub(gen::zero(), b.c1);
+    F2 r;
+    fp_dot2(a.c0.v, b.c0.v, a.c1.v, nb1.v, r.c0.v);
+    fp_dot2(a.c0.v, b.c1.v, a.c1.v, b.c0.v, r.c1.v);
+    return r;
 }
 __device__ __noinline__ F A(const F& a, const F& b) { return gen::add(a, b); }
 __device__ __noinline__ F S(const F& a, const F& b) { return gen::sub(a, b); }
