@@ -226,6 +226,11 @@ int bls381_verify_batch(bls381_ctx*, const uint8_t* pk48, const uint8_t* msg96, 
  * one; key_status (may be NULL) receives the n_keys decoder statuses.  check_subgroup_mask as above. */
 int bls381_fast_aggregate_verify(bls381_ctx*, const uint8_t* pk48, size_t n_keys, const uint8_t* msg96,
                                  const uint8_t* sig96, int check_subgroup_mask, int* valid, uint8_t* key_status);
+/* n_checks such checks at once: pk48 holds keys_per_check keys per check, check after check; one message point
+ * and one signature per check; verdict one byte per check; key_status (may be NULL) one byte per key. */
+int bls381_fast_aggregate_verify_batch(bls381_ctx*, const uint8_t* pk48, size_t n_checks, size_t keys_per_check,
+                                       const uint8_t* msg96, const uint8_t* sig96, int check_subgroup_mask,
+                                       uint8_t* verdict, uint8_t* key_status);
 
 /* ---- one G2 point against many G1 points ------------------------------------------------------
  * G2Prepared (/root/reference/src/native/miller_loop.rs:13-16, 90-119) holds the 68 line coefficients

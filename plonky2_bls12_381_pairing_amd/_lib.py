@@ -72,6 +72,7 @@ _sig("bls381_pairing_two_pairs_batch", C.c_int, ctxp, u64p, u64p, u64p, u64p, u8
 _sig("bls381_pairing_two_pairs_batch_dev", C.c_int, ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
 _sig("bls381_verify_batch", C.c_int, ctxp, u8p, u8p, u8p, C.c_size_t, C.c_int, u8p, u8p)
 _sig("bls381_fast_aggregate_verify", C.c_int, ctxp, u8p, C.c_size_t, u8p, u8p, C.c_int, C.POINTER(C.c_int), u8p)
+_sig("bls381_fast_aggregate_verify_batch", C.c_int, ctxp, u8p, C.c_size_t, C.c_size_t, u8p, u8p, C.c_int, u8p, u8p)
 _sig("bls381_debug_program", C.c_int, C.c_char_p, C.c_int, C.c_int, u32p, u32p, C.c_size_t, u32p)
 _sig("bls381_debug_constants", C.c_int, u32p, C.c_size_t)
 _sig("bls381_debug_profile", C.c_int, C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64))
@@ -93,7 +94,7 @@ EXPORTED = [
     "bls381_miller_loop_fixed_q_batch", "bls381_pairing_fixed_q_batch", "bls381_pairing_fixed_q_batch_dev", "bls381_debug_program", "bls381_debug_constants", "bls381_debug_profile", "bls381_debug_fp_mul", "bls381_debug_fp_inverse", "bls381_last_timing",
     "bls381_calibrate_mac_rate", "bls381_g1_decompress_batch", "bls381_g2_decompress_batch", "bls381_g1_compress_batch",
     "bls381_g2_compress_batch", "bls381_g1_aggregate_batch", "bls381_g2_aggregate_batch",
-    "bls381_miller_loop_two_pairs_batch", "bls381_pairing_two_pairs_batch", "bls381_pairing_two_pairs_batch_dev", "bls381_verify_batch", "bls381_fast_aggregate_verify",
+    "bls381_miller_loop_two_pairs_batch", "bls381_pairing_two_pairs_batch", "bls381_pairing_two_pairs_batch_dev", "bls381_verify_batch", "bls381_fast_aggregate_verify", "bls381_fast_aggregate_verify_batch",
 ]
 
 

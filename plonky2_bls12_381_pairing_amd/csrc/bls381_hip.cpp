@@ -1465,7 +1465,7 @@ extern "C" int bls381_verify_batch(bls381_ctx* c, const uint8_t* pk48, const uin
     hipLaunchKernelGGL(pts::fill_neg_g1_generator, grid, block, 0, c->stream, (u32*)v[B_G1B].p, m);
     uint8_t* flags = (uint8_t*)v[B_FLAGS].p;
     uint8_t* valid = flags + n;
-    hipLaunchKernelGGL(pts::verify_flags_kernel, grid, block, 0, c->stream, st, st + n, st + 2 * n, m, flags, valid);
+    hipLaunchKernelGGL(pts::verify_flags_kernel, grid, block, 0, c->stream, st, st + n, st + 2 * n, m, 0, flags, valid);
     HIPCHK(hipGetLastError());
     uint8_t* is_one = (uint8_t*)v[B_ONE].p;
     int rc = two_pairs_dev_locked(c, (const uint64_t*)v[B_G1A].p, (const uint64_t*)v[B_G2A].p, (const uint64_t*)v[B_G1B].p,
@@ -1483,71 +1483,85 @@ extern "C" int bls381_verify_batch(bls381_ctx* c, const uint8_t* pk48, const uin
     return 0;
 }
 
-// One signature over one message by n_keys signers (the sync-committee shape): keys decoded and summed on the device,
-// then e(sum, msg) * e(-G1, sig) == 1.  *valid = 1 iff every key decodes to a finite point (subgroup-checked when the
-// mask asks), message point and signature decode, and the product is one.
-extern "C" int bls381_fast_aggregate_verify(bls381_ctx* c, const uint8_t* pk48, size_t n_keys, const uint8_t* msg96,
-                                            const uint8_t* sig96, int check_subgroup, int* valid, uint8_t* key_status) {
+// n_checks aggregate checks, each one signature over one message by keys_per_check signers (the sync-committee
+// shape): keys decoded and summed on the device, then e(sum, msg) * e(-G1, sig) == 1 per check.  verdict[i] = 1 iff
+// every key of check i decodes to a finite point (subgroup-checked when the mask asks), its message point and
+// signature decode, and the product is one.
+extern "C" int bls381_fast_aggregate_verify_batch(bls381_ctx* c, const uint8_t* pk48, size_t n_checks, size_t keys_per_check,
+                                                  const uint8_t* msg96, const uint8_t* sig96, int check_subgroup,
+                                                  uint8_t* verdict, uint8_t* key_status) {
     CTX_GUARD(c);
-    if (!valid) return fail(BLS381_ERR_INVALID, "NULL buffer");
-    *valid = 0;
-    if (n_keys == 0) return 0;  // no signers: nothing verifies
-    if (!pk48 || !msg96 || !sig96) return fail(BLS381_ERR_INVALID, "NULL buffer");
-    if (n_keys > MAX_POINTS) return fail(BLS381_ERR_INVALID, "at most 2^22 keys per call");
+    if (n_checks == 0) return 0;
+    if (!pk48 || !msg96 || !sig96 || !verdict) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    if (keys_per_check == 0) { std::memset(verdict, 0, n_checks); return 0; }  // no signers: nothing verifies
+    if (keys_per_check > MAX_POINTS || n_checks > MAX_POINTS / keys_per_check)
+        return fail(BLS381_ERR_INVALID, "at most 2^22 keys per call");
     enum { B_BYTES = 0, B_G1A, B_G2A, B_G2B, B_G1B, B_STATUS, B_FLAGS, B_ONE };
     DevBuf* v = c->vbuf;
-    const size_t n = n_keys;
-    HIPCHK(v[B_BYTES].ensure(n * 48 + 192));
-    HIPCHK(v[B_G1A].ensure(n * 96 + 96));   // the keys, then their sum
-    HIPCHK(v[B_G2A].ensure(192));
-    HIPCHK(v[B_G2B].ensure(192));
-    HIPCHK(v[B_G1B].ensure(96));
-    HIPCHK(v[B_STATUS].ensure(n + 16));
-    HIPCHK(v[B_FLAGS].ensure(16));
-    HIPCHK(v[B_ONE].ensure(16));
+    const size_t g = n_checks, n = n_checks * keys_per_check;
+    HIPCHK(v[B_BYTES].ensure(n * 48 + g * 192));
+    HIPCHK(v[B_G1A].ensure(n * 96 + g * 96));  // the keys, then their sums
+    HIPCHK(v[B_G2A].ensure(g * 192));
+    HIPCHK(v[B_G2B].ensure(g * 192));
+    HIPCHK(v[B_G1B].ensure(g * 96));
+    HIPCHK(v[B_STATUS].ensure(n + 4 * g));
+    HIPCHK(v[B_FLAGS].ensure(2 * g));
+    HIPCHK(v[B_ONE].ensure(2 * g));
     while (c->pipe_ev.size() < 2) {
         hipEvent_t e;
         HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->pipe_ev.push_back(e);
     }
     uint8_t* bytes = (uint8_t*)v[B_BYTES].p;
-    uint8_t* st = (uint8_t*)v[B_STATUS].p;  // [0, n) keys, n message point, n + 1 signature, n + 2 the sum's infinity flag
-    const int m = (int)n;
-    HIPCHK(hipMemcpyAsync(bytes + n * 48, msg96, 96, hipMemcpyHostToDevice, c->copy_stream));
-    hipLaunchKernelGGL(pts::g2_decompress_kernel, dim3(1), dim3(64), 0, c->copy_stream, (const uint8_t*)bytes + n * 48, 1,
-                       (check_subgroup & BLS381_CHECK_MESSAGES) ? 1 : 0, (u32*)v[B_G2A].p, st + n);
+    uint8_t* st = (uint8_t*)v[B_STATUS].p;  // [0, n) keys; then per check: message point, signature, sum is infinity, key sum
+    uint8_t *st_msg = st + n, *st_sig = st + n + g, *sum_inf = st + n + 2 * g, *st_sum = st + n + 3 * g;
+    const int gi = (int)g;
+    const dim3 ggrid((gi + 63) / 64), block(64);
+    HIPCHK(hipMemcpyAsync(bytes + n * 48, msg96, g * 96, hipMemcpyHostToDevice, c->copy_stream));
+    hipLaunchKernelGGL(pts::g2_decompress_kernel, ggrid, block, 0, c->copy_stream, (const uint8_t*)bytes + n * 48, gi,
+                       (check_subgroup & BLS381_CHECK_MESSAGES) ? 1 : 0, (u32*)v[B_G2A].p, st_msg);
     HIPCHK(hipEventRecord(c->pipe_ev[0], c->copy_stream));
-    HIPCHK(hipMemcpyAsync(bytes + n * 48 + 96, sig96, 96, hipMemcpyHostToDevice, c->aux_stream));
-    hipLaunchKernelGGL(pts::g2_decompress_kernel, dim3(1), dim3(64), 0, c->aux_stream, (const uint8_t*)bytes + n * 48 + 96, 1,
-                       (check_subgroup & BLS381_CHECK_SIGNATURES) ? 1 : 0, (u32*)v[B_G2B].p, st + n + 1);
+    HIPCHK(hipMemcpyAsync(bytes + n * 48 + g * 96, sig96, g * 96, hipMemcpyHostToDevice, c->aux_stream));
+    hipLaunchKernelGGL(pts::g2_decompress_kernel, ggrid, block, 0, c->aux_stream, (const uint8_t*)bytes + n * 48 + g * 96, gi,
+                       (check_subgroup & BLS381_CHECK_SIGNATURES) ? 1 : 0, (u32*)v[B_G2B].p, st_sig);
     HIPCHK(hipEventRecord(c->pipe_ev[1], c->aux_stream));
     HIPCHK(hipMemcpyAsync(bytes, pk48, n * 48, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(pts::g1_decompress_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, (const uint8_t*)bytes, m,
-                       (check_subgroup & BLS381_CHECK_KEYS) ? 1 : 0, (u32*)v[B_G1A].p, st);
+    hipLaunchKernelGGL(pts::g1_decompress_kernel, dim3((unsigned)((n + 63) / 64)), block, 0, c->stream, (const uint8_t*)bytes,
+                       (int)n, (check_subgroup & BLS381_CHECK_KEYS) ? 1 : 0, (u32*)v[B_G1A].p, st);
     HIPCHK(hipGetLastError());
-    u32* sum = (u32*)v[B_G1A].p + n * 24;
-    int rc = aggregate_dev<gen::F>(c, (const u32*)v[B_G1A].p, nullptr, 1, n, sum, st + n + 2);  // rejected keys are zero points:
-    if (rc) return rc;                                                                          // the verdict below ignores the sum then
-    hipLaunchKernelGGL(pts::fill_neg_g1_generator, dim3(1), dim3(64), 0, c->stream, (u32*)v[B_G1B].p, 1);
+    u32* sums = (u32*)v[B_G1A].p + n * 24;
+    // (rejected keys are zero points: their sums mean nothing and the group status below overrides them)
+    int rc = aggregate_dev<gen::F>(c, (const u32*)v[B_G1A].p, nullptr, g, keys_per_check, sums, sum_inf);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pts::group_status_kernel, ggrid, block, 0, c->stream, (const uint8_t*)st, (const uint8_t*)sum_inf, gi,
+                       (int)keys_per_check, st_sum);
+    hipLaunchKernelGGL(pts::fill_neg_g1_generator, ggrid, block, 0, c->stream, (u32*)v[B_G1B].p, gi);
     HIPCHK(hipStreamWaitEvent(c->stream, c->pipe_ev[0], 0));
     HIPCHK(hipStreamWaitEvent(c->stream, c->pipe_ev[1], 0));
-    std::vector<uint8_t> hs(n + 3);
-    HIPCHK(hipMemcpyAsync(hs.data(), st, n + 3, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (key_status) std::memcpy(key_status, hs.data(), n);
-    for (size_t i = 0; i < n; i++)
-        if (hs[i] != BLS381_POINT_OK) return 0;  // a malformed, off-curve, off-subgroup or infinite key: not valid
-    if (hs[n] > BLS381_POINT_INFINITY || hs[n + 1] > BLS381_POINT_INFINITY) return 0;
-    const uint8_t flag = (uint8_t)((hs[n + 2] ? 1 : 0) | (hs[n] == BLS381_POINT_INFINITY ? 2 : 0) |
-                                   (hs[n + 1] == BLS381_POINT_INFINITY ? 8 : 0));
-    HIPCHK(hipMemcpyAsync(v[B_FLAGS].p, &flag, 1, hipMemcpyHostToDevice, c->stream));
-    rc = two_pairs_dev_locked(c, (const uint64_t*)sum, (const uint64_t*)v[B_G2A].p, (const uint64_t*)v[B_G1B].p,
-                              (const uint64_t*)v[B_G2B].p, (const uint8_t*)v[B_FLAGS].p, 1, nullptr, (uint8_t*)v[B_ONE].p, true);
+    uint8_t* flags = (uint8_t*)v[B_FLAGS].p;
+    uint8_t* valid = flags + g;
+    hipLaunchKernelGGL(pts::verify_flags_kernel, ggrid, block, 0, c->stream, (const uint8_t*)st_sum, (const uint8_t*)st_msg,
+                       (const uint8_t*)st_sig, gi, 1, flags, valid);
+    HIPCHK(hipGetLastError());
+    uint8_t* is_one = (uint8_t*)v[B_ONE].p;
+    rc = two_pairs_dev_locked(c, (const uint64_t*)sums, (const uint64_t*)v[B_G2A].p, (const uint64_t*)v[B_G1B].p,
+                              (const uint64_t*)v[B_G2B].p, flags, g, nullptr, is_one, true);
     if (rc) return rc;
-    uint8_t one = 0;
-    HIPCHK(hipMemcpy(&one, v[B_ONE].p, 1, hipMemcpyDeviceToHost));
-    *valid = one ? 1 : 0;
+    hipLaunchKernelGGL(pts::verify_verdict_kernel, ggrid, block, 0, c->stream, is_one, valid, gi, is_one + g);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(verdict, is_one + g, g, hipMemcpyDeviceToHost));
+    if (key_status) HIPCHK(hipMemcpy(key_status, st, n, hipMemcpyDeviceToHost));
     return 0;
+}
+extern "C" int bls381_fast_aggregate_verify(bls381_ctx* c, const uint8_t* pk48, size_t n_keys, const uint8_t* msg96,
+                                            const uint8_t* sig96, int check_subgroup, int* valid, uint8_t* key_status) {
+    if (!valid) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    uint8_t v = 0;
+    *valid = 0;
+    int rc = bls381_fast_aggregate_verify_batch(c, pk48, 1, n_keys, msg96, sig96, check_subgroup, &v, key_status);
+    if (rc == 0) *valid = v;
+    return rc;
 }
 
 // sustained v_mad_u64_u32 rate: 8 independent accumulators per lane, 8 waves per SIMD

@@ -350,13 +350,30 @@ __global__ void fill_neg_g1_generator(u32* out, int n) {
 }
 // Decoder statuses of (public key, message point, signature) -> pairing flags and a validity byte.  A key at
 // infinity is rejected (KeyValidate); a message point or signature at infinity leaves its pair out of the product.
+// (A sum of keys may be infinity without any key being so: with pk_may_be_infinity its pair is left out as well.)
 __global__ void verify_flags_kernel(const uint8_t* st_pk, const uint8_t* st_msg, const uint8_t* st_sig, int n,
-                                    uint8_t* pair_flags, uint8_t* valid) {
+                                    int pk_may_be_infinity, uint8_t* pair_flags, uint8_t* valid) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const bool ok = st_pk[i] == ST_OK && st_msg[i] <= ST_INFINITY && st_sig[i] <= ST_INFINITY;
+    const bool pk_ok = st_pk[i] == ST_OK || (pk_may_be_infinity && st_pk[i] == ST_INFINITY);
+    const bool ok = pk_ok && st_msg[i] <= ST_INFINITY && st_sig[i] <= ST_INFINITY;
     valid[i] = ok ? 1 : 0;
-    pair_flags[i] = !ok ? 15 : (uint8_t)((st_msg[i] == ST_INFINITY ? 2 : 0) | (st_sig[i] == ST_INFINITY ? 8 : 0));
+    pair_flags[i] = !ok ? 15
+                        : (uint8_t)((st_pk[i] == ST_INFINITY ? 1 : 0) | (st_msg[i] == ST_INFINITY ? 2 : 0) |
+                                    (st_sig[i] == ST_INFINITY ? 8 : 0));
+}
+// Status of each group's key sum: the worst status among its keys when any key was not a finite valid point,
+// else infinity or fine as the sum turned out.
+__global__ void group_status_kernel(const uint8_t* st_keys, const uint8_t* sum_inf, int n_groups, int group_size,
+                                    uint8_t* st_group) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    uint8_t worst = ST_OK;
+    for (int k = 0; k < group_size; k++) {
+        const uint8_t s = st_keys[(size_t)g * group_size + k];
+        if (s != ST_OK) worst = s == ST_INFINITY ? (worst > ST_BAD_ENCODING ? worst : (uint8_t)ST_BAD_ENCODING) : (s > worst ? s : worst);
+    }
+    st_group[g] = worst != ST_OK ? worst : (sum_inf[g] ? (uint8_t)ST_INFINITY : (uint8_t)ST_OK);
 }
 __global__ void verify_verdict_kernel(const uint8_t* is_one, const uint8_t* valid, int n, uint8_t* verdict) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

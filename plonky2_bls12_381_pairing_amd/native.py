@@ -396,6 +396,25 @@ class Context:
                                                _lib.C.byref(valid), _p8(status)))
         return bool(valid.value), status
 
+    def fast_aggregate_verify_batch(self, pk, msg, sig, check_subgroup=True):
+        """(checks, keys, 48) keys, (checks, 96) message points, (checks, 96) signatures ->
+        ((checks,) verdicts, (checks, keys) key statuses)."""
+        pk = np.ascontiguousarray(pk, dtype=np.uint8)
+        msg = np.ascontiguousarray(msg, dtype=np.uint8)
+        sig = np.ascontiguousarray(sig, dtype=np.uint8)
+        if pk.ndim != 3 or pk.shape[2] != 48 or msg.shape != (pk.shape[0], 96) or sig.shape != (pk.shape[0], 96):
+            raise ValueError("expected shapes (checks, keys, 48), (checks, 96), (checks, 96)")
+        if check_subgroup is True:
+            check_subgroup = 7
+        elif check_subgroup is False:
+            check_subgroup = 0
+        g, k = pk.shape[0], pk.shape[1]
+        verdict = np.zeros(g, dtype=np.uint8)
+        status = np.zeros((g, k), dtype=np.uint8)
+        check(lib.bls381_fast_aggregate_verify_batch(self._h, _p8(pk), g, k, _p8(msg), _p8(sig), int(check_subgroup),
+                                                     _p8(verdict), _p8(status)))
+        return verdict, status
+
     def pairing_witness_batch(self, g1, g2):
         g1, g2 = _arr64(g1, 12), _arr64(g2, 24)
         n = g1.shape[0]

@@ -744,3 +744,34 @@ def test_fast_aggregate_verify_from_bytes(ctx):
     valid, st = ctx.fast_aggregate_verify(broken, msg, good)
     assert not valid and st[100] == PT.BAD_ENCODING
     assert ctx.fast_aggregate_verify(pk[:0], msg, good)[0] is False
+
+
+def test_fast_aggregate_verify_batch(ctx):
+    """Four aggregate checks of 64 signers in one call: valid, wrong signature, a malformed key, and keys that sum
+    to infinity (which leaves only e(-G1, sig): valid exactly for the signature at infinity)."""
+    import random
+    import bls381_points as PT
+    rng = random.Random(64)
+    step_k = rng.randrange(1, R.R_ORDER)
+    step = R.g1_mul(R.G1_GEN, step_k)
+    k0 = rng.randrange(1, R.R_ORDER)
+    keys, ks, acc, k = [], [], R.g1_mul(R.G1_GEN, k0), k0
+    for _ in range(64):
+        keys.append(acc); ks.append(k)
+        acc = R.g1_add(acc, step); k = (k + step_k) % R.R_ORDER
+    enc = [PT.g1_compress(p) for p in keys]
+    hm = [R.g2_mul(R.G2_GEN, rng.randrange(1, R.R_ORDER)) for _ in range(4)]
+    total = sum(ks) % R.R_ORDER
+    opposite = [PT.g1_compress(p) for p in keys[:32]] + [PT.g1_compress(R.g1_neg(p)) for p in keys[:32]]
+    pk = np.stack([_bytes_array(enc), _bytes_array(enc), _bytes_array(enc), _bytes_array(opposite)])
+    pk[2, 9, 0] &= 0x7F                                              # check 2: key 9 is not in compressed form
+    msg = _bytes_array([PT.g2_compress(h) for h in hm])
+    sig = _bytes_array([PT.g2_compress(R.g2_mul(hm[0], total)), PT.g2_compress(R.g2_mul(hm[1], total + 1)),
+                        PT.g2_compress(R.g2_mul(hm[2], total)), PT.g2_compress(None)])
+    verdict, status = ctx.fast_aggregate_verify_batch(pk, msg, sig)
+    assert verdict.tolist() == [1, 0, 0, 1]
+    assert status[2, 9] == PT.BAD_ENCODING and status.sum() == PT.BAD_ENCODING
+    # check 3 with a finite signature fails
+    sig = sig.copy()
+    sig[3] = sig[0]
+    assert ctx.fast_aggregate_verify_batch(pk, msg, sig)[0].tolist() == [1, 0, 0, 0]

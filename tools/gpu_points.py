@@ -67,3 +67,9 @@ msgb, sigb = PT.g2_compress(hm), PT.g2_compress(R.g2_mul(hm, tot % R.R_ORDER))
 for label, chk in (("all inputs", 7), ("signature only", 4), ("none", 0)):
     assert ctx.fast_aggregate_verify(pk512, msgb, sigb, check_subgroup=chk)[0]
     timed("512-signer aggregate check from bytes, subgroup tests: %s" % label, lambda: ctx.fast_aggregate_verify(pk512, msgb, sigb, check_subgroup=chk), 512)
+pk_b = np.tile(pk512[None], (128, 1, 1)); msg_b = np.tile(np.frombuffer(msgb, dtype=np.uint8)[None], (128, 1))
+sig_b = np.tile(np.frombuffer(sigb, dtype=np.uint8)[None], (128, 1))
+for label, chk in (("all inputs", 7), ("none", 0)):
+    assert ctx.fast_aggregate_verify_batch(pk_b, msg_b, sig_b, check_subgroup=chk)[0].all()
+    timed("128 aggregate checks of 512 signers in one call, subgroup tests: %s" % label,
+          lambda: ctx.fast_aggregate_verify_batch(pk_b, msg_b, sig_b, check_subgroup=chk), 128)
