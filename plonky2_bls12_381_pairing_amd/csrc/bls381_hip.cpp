@@ -365,36 +365,33 @@ static int final_exp_soa(bls381_ctx* c, const void* fin, void* fout, int n, int 
 // one chunk of at most CHUNK pairs, enqueued on the context's stream (no synchronisation)
 static int miller_dev_enqueue(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags, int m,
                               uint64_t* out, bool with_final_exp) {
-    {
-        const size_t off = 0;
-        int npad = pad_elems(m);
-        HIPCHK(c->bufA.ensure(soa_bytes(6, npad)));
-        HIPCHK(c->bufB.ensure(soa_bytes(12, npad)));
-        HIPCHK(hipEventRecord(c->ev[0], c->stream));
-        int rc = pack(c, g1 + off * 12, c->bufA.p, m, npad, 2, 0);
-        if (rc) return rc;
-        rc = pack(c, g2 + off * 24, c->bufA.p, m, npad, 4, 2);
-        if (rc) return rc;
-        HIPCHK(hipEventRecord(c->ev[1], c->stream));
-        rc = run_program(c, "miller", c->bufA.p, c->bufB.p, m, npad);
-        if (rc) return rc;
-        if (flags) {
-            hipLaunchKernelGGL(set_one_where_flag, dim3((m + 255) / 256), dim3(256), 0, c->stream, (uint4*)c->bufB.p,
-                               flags + off, c->d_consts, m, npad);
-            HIPCHK(hipGetLastError());
-        }
-        HIPCHK(hipEventRecord(c->ev[2], c->stream));
-        if (with_final_exp) {
-            rc = final_exp_soa(c, c->bufB.p, c->bufB.p, m, npad, nullptr);
-            if (rc) return rc;
-        } else {
-            HIPCHK(hipEventRecord(c->ev[3], c->stream));
-        }
-        HIPCHK(hipEventRecord(c->ev[4], c->stream));
-        rc = unpack(c, c->bufB.p, out + off * 72, m, npad, 12, 0);
-        if (rc) return rc;
-        HIPCHK(hipEventRecord(c->ev[5], c->stream));
+    const int npad = pad_elems(m);
+    HIPCHK(c->bufA.ensure(soa_bytes(6, npad)));
+    HIPCHK(c->bufB.ensure(soa_bytes(12, npad)));
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    int rc = pack(c, g1, c->bufA.p, m, npad, 2, 0);
+    if (rc) return rc;
+    rc = pack(c, g2, c->bufA.p, m, npad, 4, 2);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    rc = run_program(c, "miller", c->bufA.p, c->bufB.p, m, npad);
+    if (rc) return rc;
+    if (flags) {
+        hipLaunchKernelGGL(set_one_where_flag, dim3((m + 255) / 256), dim3(256), 0, c->stream, (uint4*)c->bufB.p, flags,
+                           c->d_consts, m, npad);
+        HIPCHK(hipGetLastError());
     }
+    HIPCHK(hipEventRecord(c->ev[2], c->stream));
+    if (with_final_exp) {
+        rc = final_exp_soa(c, c->bufB.p, c->bufB.p, m, npad, nullptr);
+        if (rc) return rc;
+    } else {
+        HIPCHK(hipEventRecord(c->ev[3], c->stream));
+    }
+    HIPCHK(hipEventRecord(c->ev[4], c->stream));
+    rc = unpack(c, c->bufB.p, out, m, npad, 12, 0);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev[5], c->stream));
     return 0;
 }
 static int miller_dev_locked(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags, size_t n,
