@@ -140,10 +140,13 @@ __device__ __noinline__ F2 sqrt_fq2(const F2& a, bool& ok) {
         const u32 HALF[12] = {0xffffd556u, 0xdcff7fffu, 0x58a9ffffu, 0x0f55ffffu, 0x7b587b12u, 0xb3986950u,
                               0x79c2895fu, 0xb23ba5c2u, 0x21a5d66bu, 0x258dd3dbu, 0x1cbff34du, 0x0d0088f5u};  // (p + 1) / 2
         const F half = to_mont(HALF);
+        // x0 = ((a0 + g) / 2)^((p+1)/4) squares to +-(a0 + g) / 2.  With the plus sign the root is (x0, a1 / (2 x0)).
+        // With the minus sign (a0 - g) / 2 is the square, and since ((a0 + g) / 2)((a0 - g) / 2) = -a1^2 / 4 its root
+        // is a1 / (2 x0): the same two numbers in the other order, with no second exponentiation.
         bool sq2;
-        F x0 = sqrt_fq(mul(add(a.c0, g), half), sq2);
-        if (!sq2) x0 = sqrt_fq(mul(sub(a.c0, g), half), sq2);
-        r = {x0, mul(a.c1, inv(add(x0, x0)))};
+        const F x0 = sqrt_fq(mul(add(a.c0, g), half), sq2);
+        const F y = mul(a.c1, inv(add(x0, x0)));
+        r = sq2 ? F2{x0, y} : F2{y, x0};
     }
     const F2 chk = sqr(r);
     ok = eq(chk.c0, a.c0) && eq(chk.c1, a.c1);
