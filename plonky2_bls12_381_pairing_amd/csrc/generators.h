@@ -131,9 +131,8 @@ __device__ __noinline__ F2 sqrt_fq2(const F2& a, bool& ok) {
     F2 r;
     if (is_zero(a.c1)) {
         bool sq;
-        F s = sqrt_fq(a.c0, sq);
-        if (sq) r = {s, zero()};
-        else { bool sq2; r = {zero(), sqrt_fq(neg(a.c0), sq2)}; }  // -1 is a non-residue: -a0 is a square
+        const F s = sqrt_fq(a.c0, sq);  // s^2 = +-a0 (-1 is a non-residue); with the minus sign (s u)^2 = a0
+        r = sq ? F2{s, zero()} : F2{zero(), s};
     } else {
         bool sq;
         const F g = sqrt_fq(add(sqr(a.c0), sqr(a.c1)), sq);  // the norm must be a square in Fq
