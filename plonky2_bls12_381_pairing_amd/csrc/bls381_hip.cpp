@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -200,7 +201,11 @@ static int upload_program(bls381_ctx* c, const std::string& which) {
     std::vector<PackedDesc> blocks = pack_blocks(dp.host);
     dp.nblocks = (int)(blocks.size() / 64);
     HIPCHK(hipMalloc((void**)&dp.d_blocks, blocks.size() * sizeof(PackedDesc)));
-    HIPCHK(hipMemcpy(dp.d_blocks, blocks.data(), blocks.size() * sizeof(PackedDesc), hipMemcpyHostToDevice));
+    hipError_t e = hipMemcpy(dp.d_blocks, blocks.data(), blocks.size() * sizeof(PackedDesc), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(dp.d_blocks);
+        return fail(BLS381_ERR_HIP, std::string("program upload (") + which + "): " + hipGetErrorString(e));
+    }
     c->progs[which] = dp;
     return 0;
 }
@@ -281,12 +286,12 @@ static hipError_t launch_vm_kt(bls381_ctx* c, const DevProgram& p, const uint4* 
     // the spill array's 8-byte tails follow its 48-byte parts
     a.gtmp_tail = reinterpret_cast<uint2*>(gtmp + (size_t)std::max(1, p.host.n_tmp_slots) * 3 * npad);
     size_t lds = vm_lds_bytes(p.host.n_lds_slots, K);
-    static bool attr_set[64] = {};  // per device: a process may hold contexts on several GPUs
+    static std::atomic<bool> attr_set[64];  // per device: a process may hold contexts on several GPUs, on several threads
     const int dev = c->device & 63;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load()) {
         hipError_t e = hipFuncSetAttribute((const void*)vm_kernel<K, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set[dev] = true;
+        attr_set[dev].store(true);
     }
     int blocks = (n + GPW - 1) / GPW;
     hipLaunchKernelGGL((vm_kernel<K, TAG>), dim3(blocks), dim3(VM_THREADS), lds, c->stream, a);
