@@ -175,6 +175,17 @@ def main():
             CO.pairing_batch(g1[idx], g2[idx])
             dt_fast = time.perf_counter() - t2
             CO.set_fast(False)
+            # third figure: the reference's algorithm on one host thread (a short sample: about 2 s)
+            CO.set_threads(1)
+            n_one = int(min(nsamp, max(16, nsamp / dt / cores * 2.0)))
+            t3 = time.perf_counter()
+            CO.pairing_batch(g1[idx[:n_one]], g2[idx[:n_one]])
+            dt_one = time.perf_counter() - t3
+            CO.set_threads(cores)
+            res["cpu_baseline_one_thread"] = {
+                "value": n_one / dt_one, "unit": "pairings/s", "cores": 1, "kind": "port",
+                "sample": "the first %d of those pairings, the reference's algorithm, one thread, %.1f s" % (n_one, dt_one),
+            }
             res["cpu_baseline_optimised"] = {
                 "value": nsamp / dt_fast, "unit": "pairings/s", "cores": cores, "kind": "port",
                 "sample": "the same %d pairings with Granger-Scott cyclotomic squarings and Karatsuba tower products "
