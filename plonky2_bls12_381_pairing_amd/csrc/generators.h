@@ -66,14 +66,22 @@ __device__ __noinline__ F sqrt_candidate(const F& a) {
     // (p + 1) / 4, most significant limb first; top set bit of the top limb is bit 26
     const u32 E[12] = {0x0680447au, 0x8e5ff9a6u, 0x92c6e9edu, 0x90d2eb35u, 0xd91dd2e1u, 0x3ce144afu,
                        0xd9cc34a8u, 0x3dac3d89u, 0x07aaffffu, 0xac54ffffu, 0xee7fbfffu, 0xffffeaabu};
+    // four exponent bits at a time: 378 squarings and 92 + 14 products, against 228 products bit by bit
+    F t[16];
+    t[1] = a;
+    for (int k = 2; k < 16; k++) t[k] = mul(t[k - 1], a);
     F r = a;
     bool started = false;
     for (int w = 0; w < 12; w++)
-        for (int b = 31; b >= 0; b--) {
-            const bool bit = (E[w] >> b) & 1u;
-            if (!started) { started = bit; continue; }  // r = a stands for the leading one
-            r = sqr(r);
-            if (bit) r = mul(r, a);
+        for (int s = 28; s >= 0; s -= 4) {
+            const u32 nib = (E[w] >> s) & 15u;
+            if (!started) {  // the leading non-zero digit
+                if (nib) { r = t[nib]; started = true; }
+                continue;
+            }
+#pragma unroll 1
+            for (int q = 0; q < 4; q++) r = sqr(r);
+            if (nib) r = mul(r, t[nib]);
         }
     return r;
 }
