@@ -775,3 +775,38 @@ def test_fast_aggregate_verify_batch(ctx):
     sig = sig.copy()
     sig[3] = sig[0]
     assert ctx.fast_aggregate_verify_batch(pk, msg, sig)[0].tolist() == [1, 0, 0, 0]
+
+
+def test_concurrent_callers(ctx, CO):
+    """Several host threads on one context (calls serialise on the context's lock) and a second context on the
+    same device driven from another thread at the same time: every result equals the CPU oracle's."""
+    import threading
+    import plonky2_bls12_381_pairing_amd as B
+    ps, qs = H.random_pairs(24, 9090)
+    g1b, g2b = H.g1_array(ps), H.g2_array(qs)
+    jobs = []
+    for t in range(4):
+        n = (300, 64, 1000, 17)[t]
+        ip, iq = (np.arange(n) * (t + 1)) % 24, (np.arange(n) * 5 + t) % 24
+        jobs.append((g1b[ip], g2b[iq]))
+    other = B.Context(0)
+    results, errors = [None] * 4, []
+
+    def work(t):
+        try:
+            c = other if t == 3 else ctx
+            for _ in range(3):
+                results[t] = c.pairing_batch(*jobs[t])
+        except Exception as e:  # surfaced below: an exception in a thread would otherwise pass silently
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    other.close()
+    assert not errors, errors
+    for t in range(4):
+        probe = np.unique(np.concatenate([np.arange(0, len(jobs[t][0]), 7), [len(jobs[t][0]) - 1]]))
+        assert np.array_equal(results[t][probe], CO.pairing_batch(jobs[t][0][probe], jobs[t][1][probe])), t
