@@ -42,6 +42,26 @@ def test_no_cpu_fallback():
         B.Context(0)
 
 
+def test_argument_errors_need_no_device():
+    """Bad arguments are refused before anything touches the GPU: BLS381_ERR_INVALID and a message."""
+    L = _lib.lib
+    ctx = C.c_void_p()
+    assert L.bls381_ctx_create_ex(C.byref(ctx), 0, 7, 0) == -1 and not ctx.value
+    assert b"lanes_per_group" in L.bls381_last_error()
+    assert L.bls381_ctx_create(None, 0) == -1
+    buf = (C.c_uint64 * 72)()
+    assert L.bls381_pairing_batch(None, buf, buf, None, 1, buf) == -1
+    assert b"ctx is NULL" in L.bls381_last_error()
+    assert L.bls381_final_exp_batch(None, buf, 1, buf, None) == -1
+    assert L.bls381_pairing_witness_kinds(None, 0) == -1
+    info = (C.c_uint32 * 8)()
+    assert L.bls381_debug_program(b"no-such-program", 8, 0, None, None, 0, info) == -1
+    assert b"unknown program" in L.bls381_last_error()
+    assert L.bls381_debug_program(b"fe1", 7, 0, None, None, 0, info) == -1
+    L.bls381_ctx_destroy(None)                                # a no-op
+    L.bls381_g2_prepared_destroy(None)
+
+
 def test_constant_table():
     """The interpreter's constants carry the Montgomery factor 2^392 (14 digits of 28 bits)."""
     c = S.get_constants()
