@@ -810,3 +810,30 @@ def test_concurrent_callers(ctx, CO):
     for t in range(4):
         probe = np.unique(np.concatenate([np.arange(0, len(jobs[t][0]), 7), [len(jobs[t][0]) - 1]]))
         assert np.array_equal(results[t][probe], CO.pairing_batch(jobs[t][0][probe], jobs[t][1][probe])), t
+
+
+def test_argument_errors_on_a_live_context(ctx):
+    """NULL buffers, sizes past the documented limits and bad selectors: BLS381_ERR_INVALID, nothing launched,
+    and the context keeps working afterwards."""
+    import ctypes as C
+    from plonky2_bls12_381_pairing_amd import _lib
+    L, h = _lib.lib, ctx.handle
+    buf = (C.c_uint64 * 72)()
+    small = (C.c_uint8 * 96)()
+    assert L.bls381_pairing_batch(h, None, buf, None, 1, buf) == -1
+    assert L.bls381_pairing_batch(h, buf, buf, None, 1, None) == -1
+    assert L.bls381_pairing_batch_dev(h, None, None, None, 5, None) == -1
+    assert L.bls381_final_exp_batch(h, None, 3, buf, None) == -1
+    assert L.bls381_frobenius_batch(h, buf, 3, 1, buf) == -1
+    assert b"power" in L.bls381_last_error()
+    assert L.bls381_pairing_fixed_q_batch(h, None, buf, None, 1, buf) == -1
+    assert b"prepared" in L.bls381_last_error()
+    one = C.c_int(0)
+    assert L.bls381_multi_pairing(h, buf, buf, None, (1 << 20) + 1, buf, C.byref(one)) == -1
+    assert L.bls381_finish_multi_pairing(h, buf, 0, buf, C.byref(one)) == -1
+    assert L.bls381_g1_decompress_batch(h, small, (1 << 22) + 1, 1, buf, small) == -1
+    assert b"2^22" in L.bls381_last_error()
+    assert L.bls381_pairing_witness_batch(h, None, buf, 1, None) == -1
+    ps, qs = H.random_pairs(2, 31337)
+    out = ctx.pairing_batch(H.g1_array(ps), H.g2_array(qs))
+    assert H.fq12_from_row(out[1]) == R.native_pairing([ps[1]], [qs[1]])
