@@ -67,14 +67,21 @@ def main():
         if args.gpus != 1 or world != 1:
             raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     dist = None
-    torch.cuda.set_device(local_rank)
+    # Rehearsal of the multi-rank control flow on a box with one GPU: BLS381_BENCH_BACKEND=gloo and
+    # BLS381_BENCH_DEVICE=0 put every rank on the same card (RCCL refuses two ranks on one device).
+    backend = os.environ.get("BLS381_BENCH_BACKEND", "nccl")
+    device_index = int(os.environ.get("BLS381_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(device_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
-    ctx = B.Context(local_rank, args.lanes, args.lds_slots)
+    ctx = B.Context(device_index, args.lanes, args.lds_slots)
     g1, g2, g1b, g2b = synth_inputs(np, H, BATCH)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", device_index)
     d_g1 = torch.from_numpy(g1.view(np.int64)).to(dev)
     d_g2 = torch.from_numpy(g2.view(np.int64)).to(dev)
     d_out = torch.empty((BATCH, 72), dtype=torch.int64, device=dev)
@@ -99,7 +106,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
