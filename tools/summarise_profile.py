@@ -49,6 +49,16 @@ res["pack_kernel_calibration_KiB"] = {"FETCH_SIZE": mean(fetch["pack"]["FETCH_SI
 waves = 65536 // 8  # one wave per 8 pairings at 8 lanes each
 for label, ctr in (("valu", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU"), ("lds", "SQ_INSTS_LDS")):
     res[label + "_instructions_per_wave"] = {k: mean(sq[k][ctr]) / waves for k in ("miller", "fe2") if ctr in sq.get(k, {})}
+# VALU pipe occupancy from the same pass: a wave64 VALU instruction holds its SIMD's pipe for at least 4 cycles;
+# SQ_WAVE_CYCLES counts resident waves in units of 4 cycles, and a launch of this size keeps 2 waves on each of
+# the 1,024 SIMDs, so the kernel's duration in cycles is SQ_WAVE_CYCLES * 4 / 2048.
+res["valu_pipe_busy_share"] = {}
+for k in ("miller", "fe2"):
+    if "SQ_WAVE_CYCLES" in sq.get(k, {}):
+        kernel_cycles = mean(sq[k]["SQ_WAVE_CYCLES"]) * 4 / 2048
+        res["valu_pipe_busy_share"][k] = mean(sq[k]["SQ_INSTS_VALU"]) / 1024 * 4 / kernel_cycles
+        res.setdefault("kernel_cycles", {})[k] = kernel_cycles
+        res.setdefault("lds_bank_conflict_cycles_per_cu", {})[k] = mean(sq[k]["SQ_LDS_BANK_CONFLICT"]) / 256
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "profiles", "roofline_traffic.json"), "w"), indent=1)
 shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(ROOT, "profiles", "r1_bench_%s.json" % tag))
