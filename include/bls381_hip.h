@@ -111,8 +111,18 @@ int bls381_ell_batch(bls381_ctx*, const uint64_t* f_in, const uint64_t* coeffs, 
  * Fq12, generic squarings) as separate batch calls; ark order in and out. */
 int bls381_easy_part_batch(bls381_ctx*, const uint64_t* in_fq12, size_t n, uint64_t* out_fq12, uint8_t* is_zero_err);
 int bls381_hard_part_batch(bls381_ctx*, const uint64_t* in_fq12, size_t n, uint64_t* out_fq12);
-/* frobenius_map_native(a, power), power in {1, 2} (src/native/fin_exp_helpers.rs:10-47). */
-int bls381_frobenius_batch(bls381_ctx*, const uint64_t* in_fq12, int power, size_t n, uint64_t* out_fq12);
+/* frobenius_map_native(a, power) for any power, reduced mod 12 as the reference does
+ * (src/native/fin_exp_helpers.rs:10-47); power 0 is the identity. */
+int bls381_frobenius_batch(bls381_ctx*, const uint64_t* in_fq12, unsigned power, size_t n, uint64_t* out_fq12);
+/* conjugate_fp12 (src/native/fin_exp_helpers.rs:132-142): the coefficients of the odd powers of w change sign. */
+int bls381_conjugate_batch(bls381_ctx*, const uint64_t* in_fq12, size_t n, uint64_t* out_fq12);
+/* pow_native(a, exp) (src/native/fin_exp_helpers.rs:60-82) for any Fq12 a (generic squarings) and one exponent for
+ * the whole batch: exp = exp_words (1..6) little-endian 64-bit words, the reference's Vec<u64>.  As in the
+ * reference an exponent of zero returns a itself (its loop never starts).  bls381_pow_x_batch is
+ * pow_native(a, vec![BLS_X]), the call the hard part makes five times (final_exponentiation.rs:46-63). */
+int bls381_pow_batch(bls381_ctx*, const uint64_t* in_fq12, const uint64_t* exp, size_t exp_words, size_t n,
+                     uint64_t* out_fq12);
+int bls381_pow_x_batch(bls381_ctx*, const uint64_t* in_fq12, size_t n, uint64_t* out_fq12);
 /* Fq12 product (ark Fq12 `*`, equal to MyFq12::mul, src/utils/helpers.rs:90-152). */
 int bls381_fq12_mul_batch(bls381_ctx*, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out_fq12);
 
@@ -147,7 +157,7 @@ int bls381_final_exp_batch_dev(bls381_ctx*, const uint64_t* in_fq12_dev, size_t 
 
 /* Introspection used by the tests and the benchmark. */
 /* Builds and schedules the step program `which` ("miller", "millerfq", "miller2", "fe1", "fe2", "g2prep", "ell", "fq12mul",
- * "easy2", "hardgen", "inv1", "inv2", "frob1", "frob2") for groups of K lanes and copies it into
+ * "easy2", "hardgen", "inv1", "inv2", "conj", "frob0" .. "frob11", "pow:<16 hex digits per exponent word>") for groups of K lanes and copies it into
  * caller buffers: hdrs = nsteps x 2 u32, descs = nsteps x K x 8 u32.  info[8] receives
  * {K, nsteps, lds_slots, tmp_slots, n_in, n_out, multiply-accumulates executed (300 per product, 444 per two-product sum), n_lin}.  Pass NULL buffers to query sizes.
  * Host-only: needs no GPU. */
@@ -211,7 +221,8 @@ int bls381_g2_aggregate_batch(bls381_ctx*, const uint64_t* g2, const uint8_t* in
  * G2), the whole chain on the device: decode the three encodings as above, reject a key at infinity, then
  * native_pairing(&[pk, -G1::generator()], &[msg, sig]) == Fq12::ONE (/root/reference/src/native/pairing.rs:8-13)
  * through the two-pair call.  msg96 is the compressed hash-to-curve output of the message (hashing itself is not
- * done here).  verdict: one byte per item, 1 = the signature verifies.  status (may be NULL): 3 bytes per item,
+ * done here).  A message point at infinity is rejected like a key at infinity (verdict 0): no message hashes to it, and
+ * together with a signature at infinity it would leave an empty product.  verdict: one byte per item, 1 = the signature verifies.  status (may be NULL): 3 bytes per item,
  * the BLS381_POINT_* status of key, message point and signature.  Malformed input is a verdict of 0, not an
  * error return.  check_subgroup_mask says which of the three inputs get the order-r membership test: keys and
  * signatures come from outside; message points a caller has hashed itself are in the subgroup by construction
@@ -222,8 +233,9 @@ int bls381_verify_batch(bls381_ctx*, const uint8_t* pk48, const uint8_t* msg96, 
 
 /* One signature by n_keys signers over one message (FastAggregateVerify; the 512-key sync-committee check): keys
  * decoded and summed on the device, then native_pairing(&[sum, -G1::generator()], &[msg, sig]) == Fq12::ONE.
- * *valid = 1 iff every key decodes to a finite point, message point and signature decode, and the product is
- * one; key_status (may be NULL) receives the n_keys decoder statuses.  check_subgroup_mask as above. */
+ * *valid = 1 iff every key decodes to a finite point, the SUM of the keys is not the point at infinity (KeyValidate
+ * on the aggregate, as FastAggregateVerify's CoreVerify step does: keys such as {pk, -pk} must verify nothing),
+ * message point (finite) and signature decode, and the product is one; key_status (may be NULL) receives the n_keys decoder statuses.  check_subgroup_mask as above. */
 int bls381_fast_aggregate_verify(bls381_ctx*, const uint8_t* pk48, size_t n_keys, const uint8_t* msg96,
                                  const uint8_t* sig96, int check_subgroup_mask, int* valid, uint8_t* key_status);
 /* n_checks such checks at once: pk48 holds keys_per_check keys per check, check after check; one message point

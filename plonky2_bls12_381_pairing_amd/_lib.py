@@ -42,7 +42,10 @@ _sig("bls381_g2_prepare_batch", C.c_int, ctxp, u64p, C.c_size_t, u64p)
 _sig("bls381_ell_batch", C.c_int, ctxp, u64p, u64p, u64p, C.c_size_t, u64p)
 _sig("bls381_easy_part_batch", C.c_int, ctxp, u64p, C.c_size_t, u64p, u8p)
 _sig("bls381_hard_part_batch", C.c_int, ctxp, u64p, C.c_size_t, u64p)
-_sig("bls381_frobenius_batch", C.c_int, ctxp, u64p, C.c_int, C.c_size_t, u64p)
+_sig("bls381_frobenius_batch", C.c_int, ctxp, u64p, C.c_uint, C.c_size_t, u64p)
+_sig("bls381_conjugate_batch", C.c_int, ctxp, u64p, C.c_size_t, u64p)
+_sig("bls381_pow_batch", C.c_int, ctxp, u64p, u64p, C.c_size_t, C.c_size_t, u64p)
+_sig("bls381_pow_x_batch", C.c_int, ctxp, u64p, C.c_size_t, u64p)
 _sig("bls381_fq12_mul_batch", C.c_int, ctxp, u64p, u64p, C.c_size_t, u64p)
 _sig("bls381_fq12_inverse_limbs_batch", C.c_int, ctxp, u32p, C.c_size_t, u32p, u8p)
 _sig("bls381_pairing_witness_rows", C.c_size_t)
@@ -86,7 +89,7 @@ EXPORTED = [
     "bls381_ctx_create", "bls381_ctx_create_ex", "bls381_ctx_destroy", "bls381_last_error",
     "bls381_miller_loop_batch", "bls381_final_exp_batch", "bls381_pairing_batch", "bls381_multi_miller_loop",
     "bls381_multi_pairing", "bls381_finish_multi_pairing", "bls381_g2_prepare_batch", "bls381_ell_batch",
-    "bls381_easy_part_batch", "bls381_hard_part_batch", "bls381_frobenius_batch", "bls381_fq12_mul_batch",
+    "bls381_easy_part_batch", "bls381_hard_part_batch", "bls381_frobenius_batch", "bls381_conjugate_batch", "bls381_pow_batch", "bls381_pow_x_batch", "bls381_fq12_mul_batch",
     "bls381_fq12_inverse_limbs_batch", "bls381_pairing_witness_rows", "bls381_pairing_witness_kinds",
     "bls381_pairing_witness_batch", "bls381_pairing_witness_batch_dev", "bls381_pairing_batch_dev", "bls381_miller_loop_batch_dev",
     "bls381_final_exp_batch_dev", "bls381_g2_prepared_create", "bls381_g2_prepared_destroy",

@@ -62,8 +62,16 @@ static Dag build_named(const std::string& which) {
     if (which == "inv1") return build_fq12_inv_limbs_part1();
     if (which == "inv2") return build_fq12_inv_limbs_part2();
     if (which == "fq12mul") return build_fq12_mul();
-    if (which == "frob1") return build_frobenius(1);
-    if (which == "frob2") return build_frobenius(2);
+    if (which == "conj") return build_conjugate();
+    if (which.rfind("frob", 0) == 0 && which.size() > 4 && which.size() <= 6) {
+        const int k = atoi(which.c_str() + 4);
+        if (k >= 0 && k < 12) return build_frobenius(k);
+    }
+    if (which.rfind("pow:", 0) == 0) {  // "pow:" + 16 hex digits per 64-bit word, least significant word first
+        std::vector<uint64_t> exp;
+        for (size_t at = 4; at + 16 <= which.size(); at += 16) exp.push_back(strtoull(which.substr(at, 16).c_str(), nullptr, 16));
+        if (!exp.empty()) return build_pow(exp);
+    }
     throw std::runtime_error("unknown program " + which);
 }
 static const char* ALL_PROGRAMS[] = {"miller", "millerfq", "miller2", "g2prep", "ell",  "fe1",     "fe2",   "easy2",
@@ -124,7 +132,8 @@ struct bls381_ctx {
     uint4* d_vmconsts = nullptr;
     unsigned long long* d_prof = nullptr;  // set while bls381_debug_profile runs
     const uint4* consts_override = nullptr;  // set while a program runs against a prepared G2 point's table
-    DevBuf user_in, user_in2, user_in3, user_in4, user_out, flags, bufA, bufB, bufC, bufD, bufE, bufTmp, zflags;
+    DevBuf user_in, user_in2, user_in3, user_in4, user_out, flags, bufA, bufB, bufC, bufD, bufE, bufTmp, zflags, ilist;
+    const int* n_dev_override = nullptr;  // set while a program runs over a count that lives on the device
     DevBuf vbuf[8];  // stages of the signature check from bytes
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float last_ms[4] = {0, 0, 0, 0};  // Miller kernel, fe1 + inversion, fe2 kernel, whole device call
@@ -258,7 +267,7 @@ extern "C" void bls381_ctx_destroy(bls381_ctx* c) {
     (void)hipSetDevice(c->device);
     for (auto& kv : c->progs) (void)hipFree(kv.second.d_blocks);
     for (DevBuf* b : {&c->user_in, &c->user_in2, &c->user_in3, &c->user_in4, &c->user_out, &c->flags, &c->bufA, &c->bufB,
-                      &c->bufC, &c->bufD, &c->bufE, &c->bufTmp, &c->zflags})
+                      &c->bufC, &c->bufD, &c->bufE, &c->bufTmp, &c->zflags, &c->ilist})
         b->release();
     for (auto& b : c->vbuf) b.release();
     c->wit.release();
@@ -282,7 +291,7 @@ static hipError_t launch_vm_kt(bls381_ctx* c, const DevProgram& p, const uint4* 
     constexpr int GPW = 4 * (64 / K);
     VmArgs a;
     a.blocks = p.d_blocks; a.nblocks = p.nblocks; a.nsteps = (int)p.host.hdrs.size(); a.lds_slots = p.host.n_lds_slots;
-    a.prof = c->d_prof; a.consts = c->consts_override ? c->consts_override : c->d_vmconsts; a.gin = gin; a.gout = gout; a.gtmp = gtmp; a.n = n; a.npad = npad;
+    a.prof = c->d_prof; a.consts = c->consts_override ? c->consts_override : c->d_vmconsts; a.gin = gin; a.gout = gout; a.gtmp = gtmp; a.n = n; a.npad = npad; a.n_dev = c->n_dev_override;
     // the spill array's 8-byte tails follow its 48-byte parts
     a.gtmp_tail = reinterpret_cast<uint2*>(gtmp + (size_t)std::max(1, p.host.n_tmp_slots) * 3 * npad);
     size_t lds = vm_lds_bytes(p.host.n_lds_slots, K);
@@ -308,6 +317,23 @@ static hipError_t launch_vm_k(bls381_ctx* c, const DevProgram& p, const uint4* g
 }
 
 enum { SMALL_BATCH = 8192 };
+// Launches program `which` (exactly that variant; it must have been uploaded) with the caller's spill array.
+static int run_program_on(bls381_ctx* c, const std::string& which, const void* gin, void* gout, void* gtmp, int n, int npad) {
+    auto it = c->progs.find(which);
+    if (it == c->progs.end()) return fail(BLS381_ERR_INVALID, std::string("no program ") + which);
+    const DevProgram& p = it->second;
+    hipError_t e;
+    switch (p.host.K) {
+        case 6: e = launch_vm_k<6>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)gtmp, n, npad); break;
+        case 8: e = launch_vm_k<8>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)gtmp, n, npad); break;
+        case 9: e = launch_vm_k<9>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)gtmp, n, npad); break;
+        case 12: e = launch_vm_k<12>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)gtmp, n, npad); break;
+        default: e = launch_vm_k<16>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)gtmp, n, npad); break;
+    }
+    if (e != hipSuccess) return fail(BLS381_ERR_HIP, std::string("vm_kernel launch (") + which + "): " + hipGetErrorString(e));
+    return 0;
+}
+static size_t spill_bytes(const DevProgram& p, int npad) { return (size_t)std::max(1, p.host.n_tmp_slots) * 56 * npad; }
 static int run_program(bls381_ctx* c, const char* which_c, const void* gin, void* gout, int n, int npad) {
     std::string which = which_c;
     if (c->auto_geometry && n <= SMALL_BATCH && which != "miller2" && which.rfind("t_", 0) != 0) {
@@ -317,20 +343,13 @@ static int run_program(bls381_ctx* c, const char* which_c, const void* gin, void
             if (rc) return rc;
         }
     }
-    auto it = c->progs.find(which);
-    if (it == c->progs.end()) return fail(BLS381_ERR_INVALID, std::string("no program ") + which);
-    const DevProgram& p = it->second;
-    HIPCHK(c->bufTmp.ensure((size_t)std::max(1, p.host.n_tmp_slots) * 56 * npad));
-    hipError_t e;
-    switch (p.host.K) {
-        case 6: e = launch_vm_k<6>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)c->bufTmp.p, n, npad); break;
-        case 8: e = launch_vm_k<8>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)c->bufTmp.p, n, npad); break;
-        case 9: e = launch_vm_k<9>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)c->bufTmp.p, n, npad); break;
-        case 12: e = launch_vm_k<12>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)c->bufTmp.p, n, npad); break;
-        default: e = launch_vm_k<16>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)c->bufTmp.p, n, npad); break;
+    if (!c->progs.count(which)) {  // programs outside the start-up set are built on first use
+        int rc = upload_program(c, which);
+        if (rc) return rc;
     }
-    if (e != hipSuccess) return fail(BLS381_ERR_HIP, std::string("vm_kernel launch (") + which + "): " + hipGetErrorString(e));
-    return 0;
+    auto it = c->progs.find(which);
+    HIPCHK(c->bufTmp.ensure(spill_bytes(it->second, npad)));
+    return run_program_on(c, which, gin, gout, c->bufTmp.p, n, npad);
 }
 
 static int pack(bls381_ctx* c, const void* aos_dev, void* soa, int n, int npad, int fp_per_elem, int slot0) {
@@ -424,12 +443,6 @@ static int miller_dev_locked(bls381_ctx* c, const uint64_t* g1, const uint64_t* 
 static int two_pairs_dev_locked(bls381_ctx* c, const uint64_t* g1a, const uint64_t* g2a, const uint64_t* g1b,
                                 const uint64_t* g2b, const uint8_t* flags, size_t n, uint64_t* out, uint8_t* is_one,
                                 bool with_final_exp) {
-    std::vector<uint8_t> hflags;
-    if (flags) {
-        hflags.resize(n);
-        HIPCHK(hipMemcpyAsync(hflags.data(), flags, n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-    }
     for (size_t off = 0; off < n; off += CHUNK) {
         int m = (int)std::min<size_t>(CHUNK, n - off);
         int npad = pad_elems(m);
@@ -443,15 +456,27 @@ static int two_pairs_dev_locked(bls381_ctx* c, const uint64_t* g1a, const uint64
         if ((rc = pack(c, g2b + off * 24, c->bufA.p, m, npad, 4, 8))) return rc;
         HIPCHK(hipEventRecord(c->ev[1], c->stream));
         if ((rc = run_program(c, "miller2", c->bufA.p, c->bufB.p, m, npad))) return rc;
-        bool any = false;
-        for (int i = 0; flags && i < m; i++) any = any || (hflags[off + i] & 15u);
-        if (any) {  // rare: the pairs' own Miller values for the items that skip one
-            HIPCHK(c->bufD.ensure(soa_bytes(12, npad)));
+        if (flags) {
+            // Items that skip one pair (a point at infinity) need the other pair's own Miller value.  They are
+            // picked out on the device (no copy of the flags to the host, no synchronisation): their remaining
+            // pairs are gathered into a compact slot array, the single-pair program runs over as many of them
+            // as there are (the count stays on the device; workgroups beyond it exit at once), and the results
+            // are scattered back.  A batch in which every item is flagged costs one extra Miller loop, not two.
+            HIPCHK(c->bufD.ensure(soa_bytes(6, npad)));
             HIPCHK(c->bufE.ensure(soa_bytes(12, npad)));
-            if ((rc = run_program(c, "miller", c->bufA.p, c->bufD.p, m, npad))) return rc;
-            if ((rc = run_program(c, "miller", (const char*)c->bufA.p + soa_bytes(6, npad), c->bufE.p, m, npad))) return rc;
-            hipLaunchKernelGGL(select_two_pairs, dim3((m + 255) / 256), dim3(256), 0, c->stream, (uint4*)c->bufB.p,
-                               (const uint4*)c->bufD.p, (const uint4*)c->bufE.p, flags + off, c->d_consts, m, npad);
+            HIPCHK(c->ilist.ensure((size_t)(m + 1) * sizeof(int)));
+            int* count = (int*)c->ilist.p;
+            int* list = count + 1;
+            HIPCHK(hipMemsetAsync(count, 0, sizeof(int), c->stream));
+            hipLaunchKernelGGL(compact_one_pair_items, dim3((m + 255) / 256), dim3(256), 0, c->stream, (const uint4*)c->bufA.p,
+                               flags + off, m, npad, (uint4*)c->bufD.p, list, count);
+            HIPCHK(hipGetLastError());
+            c->n_dev_override = count;
+            rc = run_program(c, "miller", c->bufD.p, c->bufE.p, m, npad);
+            c->n_dev_override = nullptr;
+            if (rc) return rc;
+            hipLaunchKernelGGL(scatter_one_pair_items, dim3((m + 255) / 256), dim3(256), 0, c->stream, (uint4*)c->bufB.p,
+                               (const uint4*)c->bufE.p, flags + off, (const int*)list, (const int*)count, c->d_consts, m, npad);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(c->ev[2], c->stream));
@@ -921,10 +946,37 @@ extern "C" int bls381_hard_part_batch(bls381_ctx* c, const uint64_t* in, size_t 
     CTX_GUARD(c);
     return simple_host(c, "hardgen", {{in, 12}}, n, out, 12);
 }
-extern "C" int bls381_frobenius_batch(bls381_ctx* c, const uint64_t* in, int power, size_t n, uint64_t* out) {
+extern "C" int bls381_frobenius_batch(bls381_ctx* c, const uint64_t* in, unsigned power, size_t n, uint64_t* out) {
     CTX_GUARD(c);
-    if (power != 1 && power != 2) return fail(BLS381_ERR_INVALID, "power must be 1 or 2");
-    return simple_host(c, power == 1 ? "frob1" : "frob2", {{in, 12}}, n, out, 12);
+    const std::string prog = "frob" + std::to_string(power % 12);  // the reference reduces the power mod 12
+    return simple_host(c, prog.c_str(), {{in, 12}}, n, out, 12);
+}
+extern "C" int bls381_conjugate_batch(bls381_ctx* c, const uint64_t* in, size_t n, uint64_t* out) {
+    CTX_GUARD(c);
+    return simple_host(c, "conj", {{in, 12}}, n, out, 12);
+}
+extern "C" int bls381_pow_batch(bls381_ctx* c, const uint64_t* in, const uint64_t* exp, size_t exp_words, size_t n, uint64_t* out) {
+    CTX_GUARD(c);
+    if (!exp || exp_words == 0 || exp_words > 6) return fail(BLS381_ERR_INVALID, "the exponent is 1 to 6 words of 64 bits");
+    std::string prog = "pow:";
+    char buf[17];
+    for (size_t i = 0; i < exp_words; i++) { snprintf(buf, sizeof buf, "%016llx", (unsigned long long)exp[i]); prog += buf; }
+    // one program per distinct exponent stays resident; a caller cycling through many exponents would fill the
+    // device with them, so only a few are kept
+    if (!c->progs.count(prog)) {
+        size_t have = 0;
+        for (auto& kv : c->progs) have += kv.first.rfind("pow:", 0) == 0;
+        if (have >= 16) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            for (auto it = c->progs.begin(); it != c->progs.end();)
+                if (it->first.rfind("pow:", 0) == 0) { (void)hipFree(it->second.d_blocks); it = c->progs.erase(it); } else ++it;
+        }
+    }
+    return simple_host(c, prog.c_str(), {{in, 12}}, n, out, 12);
+}
+extern "C" int bls381_pow_x_batch(bls381_ctx* c, const uint64_t* in, size_t n, uint64_t* out) {
+    const uint64_t x = BLS381_X;
+    return bls381_pow_batch(c, in, &x, 1, n, out);
 }
 extern "C" int bls381_fq12_mul_batch(bls381_ctx* c, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
     CTX_GUARD(c);
@@ -1467,7 +1519,7 @@ extern "C" int bls381_verify_batch(bls381_ctx* c, const uint8_t* pk48, const uin
     hipLaunchKernelGGL(pts::fill_neg_g1_generator, grid, block, 0, c->stream, (u32*)v[B_G1B].p, m);
     uint8_t* flags = (uint8_t*)v[B_FLAGS].p;
     uint8_t* valid = flags + n;
-    hipLaunchKernelGGL(pts::verify_flags_kernel, grid, block, 0, c->stream, st, st + n, st + 2 * n, m, 0, flags, valid);
+    hipLaunchKernelGGL(pts::verify_flags_kernel, grid, block, 0, c->stream, st, st + n, st + 2 * n, m, flags, valid);
     HIPCHK(hipGetLastError());
     uint8_t* is_one = (uint8_t*)v[B_ONE].p;
     int rc = two_pairs_dev_locked(c, (const uint64_t*)v[B_G1A].p, (const uint64_t*)v[B_G2A].p, (const uint64_t*)v[B_G1B].p,
@@ -1543,7 +1595,7 @@ extern "C" int bls381_fast_aggregate_verify_batch(bls381_ctx* c, const uint8_t* 
     uint8_t* flags = (uint8_t*)v[B_FLAGS].p;
     uint8_t* valid = flags + g;
     hipLaunchKernelGGL(pts::verify_flags_kernel, ggrid, block, 0, c->stream, (const uint8_t*)st_sum, (const uint8_t*)st_msg,
-                       (const uint8_t*)st_sig, gi, 1, flags, valid);
+                       (const uint8_t*)st_sig, gi, flags, valid);
     HIPCHK(hipGetLastError());
     uint8_t* is_one = (uint8_t*)v[B_ONE].p;
     rc = two_pairs_dev_locked(c, (const uint64_t*)sums, (const uint64_t*)v[B_G2A].p, (const uint64_t*)v[B_G1B].p,

@@ -349,18 +349,17 @@ __global__ void fill_neg_g1_generator(u32* out, int n) {
     for (int k = 0; k < 12; k++) { out[(size_t)i * 24 + k] = X[k]; out[(size_t)i * 24 + 12 + k] = Y[k]; }
 }
 // Decoder statuses of (public key, message point, signature) -> pairing flags and a validity byte.  A key at
-// infinity is rejected (KeyValidate); a message point or signature at infinity leaves its pair out of the product.
-// (A sum of keys may be infinity without any key being so: with pk_may_be_infinity its pair is left out as well.)
+// infinity is rejected (KeyValidate), and so is a sum of keys that comes out as infinity (FastAggregateVerify runs
+// KeyValidate on the aggregate: {pk, -pk} must not verify anything) and a message point at infinity (no message
+// hashes to it; with a signature at infinity it would make the product empty, i.e. one, under any key).  A signature
+// at infinity only leaves its pair out of the product, which then cannot be one.
 __global__ void verify_flags_kernel(const uint8_t* st_pk, const uint8_t* st_msg, const uint8_t* st_sig, int n,
-                                    int pk_may_be_infinity, uint8_t* pair_flags, uint8_t* valid) {
+                                    uint8_t* pair_flags, uint8_t* valid) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const bool pk_ok = st_pk[i] == ST_OK || (pk_may_be_infinity && st_pk[i] == ST_INFINITY);
-    const bool ok = pk_ok && st_msg[i] <= ST_INFINITY && st_sig[i] <= ST_INFINITY;
+    const bool ok = st_pk[i] == ST_OK && st_msg[i] == ST_OK && st_sig[i] <= ST_INFINITY;
     valid[i] = ok ? 1 : 0;
-    pair_flags[i] = !ok ? 15
-                        : (uint8_t)((st_pk[i] == ST_INFINITY ? 1 : 0) | (st_msg[i] == ST_INFINITY ? 2 : 0) |
-                                    (st_sig[i] == ST_INFINITY ? 8 : 0));
+    pair_flags[i] = !ok ? 15 : (uint8_t)(st_sig[i] == ST_INFINITY ? 8 : 0);
 }
 // Status of each group's key sum: the worst status among its keys when any key was not a finite valid point,
 // else infinity or fine as the sum turned out.

@@ -98,7 +98,10 @@ Dag build_fq12_inv_limbs_part1();
 Dag build_fq12_inv_limbs_part2();
 // Fq12 product (ark order in and out): gin a (12) + b (12) -> gout 12.
 Dag build_fq12_mul();
-// frobenius_map_native(a, power) for power in {1, 2}, ark order in/out.
+// frobenius_map_native(a, power) for any power (taken mod 12), ark order in/out.
 Dag build_frobenius(int power);
+// conjugate_fp12 and pow_native(a, exp) (exp: little-endian 64-bit words), ark order in/out.
+Dag build_conjugate();
+Dag build_pow(const std::vector<uint64_t>& exp);
 
 }  // namespace bls381

@@ -187,7 +187,16 @@ SFq12 Tower::cyclotomic_sqr(const SFq12& a) {
 // Coefficient i of w^i is conjugated (odd power) and multiplied by gamma_power^i.
 // /root/reference/src/native/fin_exp_helpers.rs:10-47; the constants are precomputed.
 SFq12 Tower::frobenius(const SFq12& a, int power) {
-    assert(power == 1 || power == 2);
+    power %= 12;
+    if (power != 1 && power != 2) {
+        // The map is the power-th iterate of the Frobenius automorphism (gamma_k^i = xi^(i (p^k - 1) / 6) is what
+        // k applications multiply coefficient i by), so any power is composed from the two whose constants
+        // are tabulated; field elements are canonical, so the value is the reference's.
+        SFq12 r = a;
+        for (int k = 0; k < power / 2; k++) r = frobenius(r, 2);
+        if (power & 1) r = frobenius(r, 1);
+        return r;
+    }
     // w-basis: A0 = c0.c0, A1 = c1.c0, A2 = c0.c1, A3 = c1.c1, A4 = c0.c2, A5 = c1.c2
     const SFq2* A[6] = {&a.c0.c0, &a.c1.c0, &a.c0.c1, &a.c1.c1, &a.c0.c2, &a.c1.c2};
     SFq2 B[6];
@@ -213,6 +222,21 @@ SFq12 Tower::pow_x(const SFq12& a, bool cyclotomic) {
     for (int i = 62; i >= 0; i--) {
         res = cyclotomic ? cyclotomic_sqr(res) : sqr(res);
         if ((BLS381_X >> i) & 1) res = mul(res, a);
+    }
+    return res;
+}
+
+// pow_native for any exponent (little-endian 64-bit words, as the reference's Vec<u64>): its get_naf
+// never carries and both digit signs multiply by a, so it is MSB-first binary exponentiation; an
+// exponent of zero returns a itself (the loop never starts), /root/reference/src/native/fin_exp_helpers.rs:60-82.
+SFq12 Tower::pow(const SFq12& a, const std::vector<uint64_t>& exp) {
+    int top = -1;
+    for (int i = (int)exp.size() * 64 - 1; i >= 0 && top < 0; i--)
+        if ((exp[i / 64] >> (i % 64)) & 1) top = i;
+    SFq12 res = a;
+    for (int i = top - 1; i >= 0; i--) {
+        res = sqr(res);
+        if ((exp[i / 64] >> (i % 64)) & 1) res = mul(res, a);
     }
     return res;
 }
@@ -546,6 +570,26 @@ Dag build_fq12_mul() {
     d.n_in = 24; d.n_out = 12;
     Tower T(d);
     T.out12(T.mul(T.in12(0), T.in12(12)), 0);
+    d.optimise();
+    return d;
+}
+
+// conjugate_fp12 (/root/reference/src/native/fin_exp_helpers.rs:132-142): the odd powers of w change sign,
+// i.e. c1 -> -c1 in the tower; ark order in and out.
+Dag build_conjugate() {
+    Dag d;
+    d.n_in = 12; d.n_out = 12;
+    Tower T(d);
+    T.out12(T.conj(T.in12(0)), 0);
+    d.optimise();
+    return d;
+}
+
+Dag build_pow(const std::vector<uint64_t>& exp) {
+    Dag d;
+    d.n_in = 12; d.n_out = 12;
+    Tower T(d);
+    T.out12(T.pow(T.in12(0), exp), 0);
     d.optimise();
     return d;
 }

@@ -4,6 +4,7 @@
 //
 // Tower (ark-bls12-381): Fq2 = Fq[u]/(u^2+1), Fq6 = Fq2[v]/(v^3-(1+u)), Fq12 = Fq6[w]/(w^2-v).
 #pragma once
+#include <cstdint>
 #include <initializer_list>
 #include <utility>
 #include <vector>
@@ -80,7 +81,8 @@ class Tower {
     SFq12 conj(const SFq12& a) { return {a.c0, neg(a.c1)}; }
     SFq12 mul_by_014(const SFq12& f, const SFq2& c0, const SFq2& c1, const SFq2& c4);
     SFq12 cyclotomic_sqr(const SFq12& a);
-    SFq12 frobenius(const SFq12& a, int power);  // power in {1, 2}
+    SFq12 frobenius(const SFq12& a, int power);  // any power (taken mod 12)
+    SFq12 pow(const SFq12& a, const std::vector<uint64_t>& exp);  // generic squarings, any exponent
     SFq12 pow_x(const SFq12& a, bool cyclotomic);  // a^|x|, MSB-first binary
 
     // Fq12 inverse split around the Fp inversion.

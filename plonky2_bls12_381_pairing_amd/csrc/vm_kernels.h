@@ -28,6 +28,7 @@ struct VmArgs {
     uint4* gtmp;
     uint2* gtmp_tail;
     int n;     // number of groups (pairings) with work
+    const int* n_dev;  // when set: a count in device memory that further limits n (workgroups beyond it exit at once)
     int npad;  // element stride of the global slot arrays
     unsigned long long* prof;  // TAG_PROFILE only: [0..16) cycles per step kind, [16..32) step counts
 };
@@ -59,6 +60,8 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
     extern __shared__ uint4 lds[];
     uint2* lds_tail = reinterpret_cast<uint2*>(lds + (size_t)A.lds_slots * 3 * GPW);
 
+    const int n_groups = A.n_dev ? min(A.n, *A.n_dev) : A.n;
+    if ((long)blockIdx.x * GPW >= n_groups) return;  // uniform over the workgroup
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int role_raw = lane / G;
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
     const int g = wave * G + gw;
     const int role = role_raw < K ? role_raw : 0;
     const long e = (long)blockIdx.x * GPW + g;
-    const bool lane_on = (role_raw < K) && (e < A.n);
+    const bool lane_on = (role_raw < K) && (e < n_groups);
 
     // the ZERO slot (second to last) of every group
     for (int i = tid; i < 3 * GPW; i += VM_THREADS) lds[(size_t)(A.lds_slots - 2) * 3 * GPW + i] = make_uint4(0, 0, 0, 0);
@@ -363,21 +366,35 @@ __global__ void set_one_where_flag(uint4* soa, const uint8_t* flags, const uint4
     }
 }
 
-// Two-pair items with a pair at infinity: bits 0..1 of flags[e] skip the first pair, bits 2..3 the
-// second.  Both skipped -> one; one skipped -> the other pair's own Miller value (only_a / only_b).
-__global__ void select_two_pairs(uint4* soa, const uint4* only_a, const uint4* only_b, const uint8_t* flags,
-                                 const uint4* consts, int n, int npad) {
+// Two-pair items with a pair at infinity: bits 0..1 of flags[e] skip the first pair, bits 2..3 the second.
+// Items that skip exactly one pair: the other pair's inputs (P: 2 slots, Q: 4 slots of the 12-slot input array) are
+// gathered into a compact 6-slot array in list order; *count ends up as their number.
+__global__ void compact_one_pair_items(const uint4* soa, const uint8_t* flags, int n, int npad, uint4* out, int* list,
+                                       int* count) {
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     const bool skip_a = flags[e] & 3u, skip_b = flags[e] & 12u;
-    if (!skip_a && !skip_b) return;
+    if (skip_a == skip_b) return;
+    const int k = atomicAdd(count, 1);
+    list[k] = (int)e;
+    const int base = skip_a ? 6 : 0;
+    for (int f = 0; f < 6; f++)
+        for (int c = 0; c < 3; c++) out[((size_t)f * 3 + c) * npad + k] = soa[((size_t)(base + f) * 3 + c) * npad + e];
+}
+// Puts the single-pair Miller values (`only`, in list order) in their items' places and one where both pairs are skipped.
+__global__ void scatter_one_pair_items(uint4* soa, const uint4* only, const uint8_t* flags, const int* list, const int* count,
+                                       const uint4* consts, int n, int npad) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
     const uint4 z = make_uint4(0, 0, 0, 0);
-    for (int f = 0; f < 12; f++)
-        for (int k = 0; k < 3; k++) {
-            const size_t at = ((size_t)f * 3 + k) * npad + e;
-            if (skip_a && skip_b) soa[at] = f == 0 ? consts[C_ONE * 3 + k] : z;
-            else soa[at] = skip_a ? only_b[at] : only_a[at];
-        }
+    if ((flags[e] & 3u) && (flags[e] & 12u))
+        for (int f = 0; f < 12; f++)
+            for (int c = 0; c < 3; c++) soa[((size_t)f * 3 + c) * npad + e] = f == 0 ? consts[C_ONE * 3 + c] : z;
+    if (e < *count) {
+        const int item = list[e];
+        for (int f = 0; f < 12; f++)
+            for (int c = 0; c < 3; c++) soa[((size_t)f * 3 + c) * npad + item] = only[((size_t)f * 3 + c) * npad + e];
+    }
 }
 // flags[e] = 1 when the Fq12 in slots 0..11 equals one
 __global__ void is_one_kernel(const uint4* soa, const uint4* consts, int n, int npad, uint8_t* flags) {

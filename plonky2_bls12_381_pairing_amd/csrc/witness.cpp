@@ -499,6 +499,7 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
                        uint32_t* trace, std::string& err, bool on_device) {
     const WitnessProgram& P = witness_program();
     if (!uploaded_) {
+        release();  // an earlier upload that failed half-way leaves nothing behind
         for (int ph = 0; ph < 2; ph++) {
             WCHK(hipMalloc((void**)&d_ops_[ph], P.ops[ph].size() * sizeof(WitnessOp)));
             WCHK(hipMalloc((void**)&d_levels_[ph], P.level_start[ph].size() * 4));
@@ -522,9 +523,15 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
     // its copy back to the host is what bounds it anyway.
     size_t CH = on_device ? 16384 : 1024;
     int block = 64, lpp = 16;
-    if (const char* e = getenv("BLS381_WIT_CH")) CH = (size_t)atol(e);
+    // tuning overrides; out-of-range values are errors (a stride of 0 would never advance the loop below)
+    if (const char* e = getenv("BLS381_WIT_CH")) {
+        const long v = atol(e);
+        if (v < 1 || v > 16384) { err = "BLS381_WIT_CH must be in 1..16384"; return -1; }
+        CH = (size_t)v;
+    }
     if (const char* e = getenv("BLS381_WIT_BLOCK")) block = atoi(e);
     if (const char* e = getenv("BLS381_WIT_LPP")) lpp = atoi(e);
+    if (block < 1 || block > 1024 || block % 64) { err = "BLS381_WIT_BLOCK must be a multiple of 64 up to 1024"; return -1; }
     if (lpp < 1 || lpp > block || block % lpp) { err = "BLS381_WIT_LPP must divide BLS381_WIT_BLOCK"; return -1; }
     const int per_block = block / lpp;
     for (size_t off = 0; off < n; off += CH) {

@@ -150,6 +150,8 @@ class Context:
         """ell(f, coeffs, p) (miller_loop.rs:185-194)."""
         f, coeffs, g1 = _arr64(f, 72), _arr64(coeffs, 36), _arr64(g1, 12)
         n = f.shape[0]
+        if coeffs.shape[0] != n or g1.shape[0] != n:
+            raise ValueError("f, coeffs and g1 must have one row per item")
         out = np.empty((n, 72), dtype=np.uint64)
         check(lib.bls381_ell_batch(self._h, _p64(f), _p64(coeffs), _p64(g1), n, _p64(out)))
         return out
@@ -185,9 +187,43 @@ class Context:
         check(lib.bls381_frobenius_batch(self._h, _p64(fq12), power, n, _p64(out)))
         return out
 
+    def conjugate_batch(self, fq12):
+        """conjugate_fp12 (fin_exp_helpers.rs:132-142) per element."""
+        fq12 = _arr64(fq12, 72)
+        n = fq12.shape[0]
+        out = np.empty((n, 72), dtype=np.uint64)
+        check(lib.bls381_conjugate_batch(self._h, _p64(fq12), n, _p64(out)))
+        return out
+
+    def pow_native_batch(self, fq12, exp):
+        """pow_native(a, exp) (fin_exp_helpers.rs:60-82) per element; exp: a non-negative int below 2^384 or a list
+        of little-endian 64-bit words (the reference's Vec<u64>)."""
+        fq12 = _arr64(fq12, 72)
+        n = fq12.shape[0]
+        if isinstance(exp, int):
+            if exp < 0 or exp >> 384:
+                raise ValueError("exponent out of range")
+            words = [(exp >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(max(1, (exp.bit_length() + 63) // 64))]
+        else:
+            words = [int(w) for w in exp]
+        e = np.array(words, dtype=np.uint64)
+        out = np.empty((n, 72), dtype=np.uint64)
+        check(lib.bls381_pow_batch(self._h, _p64(fq12), _p64(e), len(words), n, _p64(out)))
+        return out
+
+    def pow_x_batch(self, fq12):
+        """pow_native(a, vec![BLS_X])."""
+        fq12 = _arr64(fq12, 72)
+        n = fq12.shape[0]
+        out = np.empty((n, 72), dtype=np.uint64)
+        check(lib.bls381_pow_x_batch(self._h, _p64(fq12), n, _p64(out)))
+        return out
+
     def fq12_mul_batch(self, a, b):
         a, b = _arr64(a, 72), _arr64(b, 72)
         n = a.shape[0]
+        if b.shape[0] != n:
+            raise ValueError("a and b must have one row per item")
         out = np.empty((n, 72), dtype=np.uint64)
         check(lib.bls381_fq12_mul_batch(self._h, _p64(a), _p64(b), n, _p64(out)))
         return out
@@ -418,6 +454,8 @@ class Context:
     def pairing_witness_batch(self, g1, g2):
         g1, g2 = _arr64(g1, 12), _arr64(g2, 24)
         n = g1.shape[0]
+        if g2.shape[0] != n:
+            raise ValueError("g1 and g2 must have one row per proof")
         rows = lib.bls381_pairing_witness_rows()
         trace = np.empty((n, rows, 12), dtype=np.uint32)
         check(lib.bls381_pairing_witness_batch(self._h, _p64(g1), _p64(g2), n, _p32(trace)))

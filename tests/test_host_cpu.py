@@ -106,9 +106,14 @@ def test_auxiliary_programs():
     run = lambda name, gin: [F(x) for x in S.run_program(S.get_program(name), [M(v) for v in gin])]
     assert R.fq12_from_flat_ark(run("fq12mul", fa + fb)) == R.fq12_mul(a, b)
     assert R.fq12_from_flat_ark(run("hardgen", fa)) == R.hard_part_native(a)
-    for pw in (1, 2):
+    for pw in (0, 1, 2, 3, 6, 7, 11):
         want = R.myfq12_to_fq12(R.frobenius_map_native(R.myfq12_from_fq12(a), pw))
         assert R.fq12_from_flat_ark(run("frob%d" % pw, fa)) == want
+    assert R.fq12_from_flat_ark(run("conj", fa)) == R.fq12_conj(a)
+    for exp in (0, 0xb, (5 << 64) | 3):                      # pow_native: the program name carries the exponent words
+        name = "pow:" + "".join("%016x" % ((exp >> (64 * i)) & (2 ** 64 - 1)) for i in range(max(1, (exp.bit_length() + 63) // 64)))
+        want = R.myfq12_to_fq12(R.pow_native(R.myfq12_from_fq12(a), exp))
+        assert R.fq12_from_flat_ark(run(name, fa)) == want
     p = R.g1_mul(R.G1_GEN, 5)
     c = tuple((fb[2 * i], fb[2 * i + 1]) for i in range(3))
     assert R.fq12_from_flat_ark(run("ell", fa + fb[:6] + [p[0], p[1]])) == R.ell(a, c, p)
