@@ -155,6 +155,18 @@ int bls381_miller_loop_batch_dev(bls381_ctx*, const uint64_t* g1_dev, const uint
 int bls381_final_exp_batch_dev(bls381_ctx*, const uint64_t* in_fq12_dev, size_t n, uint64_t* out_fq12_dev,
                                uint8_t* is_zero_err_dev);
 
+/* bls381_pairing_batch_dev for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same kernels and results as
+ * bls381_pairing_batch_dev, but the workspace (slot arrays, carry and spill arrays) is a fixed 32 MiB array that
+ * the library holds in each GPU's memory from load to process exit; the call makes no hipMalloc / hipFree.
+ * n is at most BLS381_NOALLOC_MAX_PAIRS (larger n: BLS381_ERR_INVALID, nothing runs).  All calls on one GPU share
+ * that array, from every context on it: two such calls that overlap in time on one GPU race, the caller
+ * serialises them (calls on one context already are).  Nothing in the array needs clearing between calls:
+ * every location is written before it is read. */
+enum { BLS381_NOALLOC_MAX_PAIRS = 4096 };
+int bls381_pairing_batch_dev_noalloc(bls381_ctx*, const uint64_t* g1_dev, const uint64_t* g2_dev,
+                                     const uint8_t* inf_flags_dev, size_t n, uint64_t* out_fq12_dev);
+
 /* Introspection used by the tests and the benchmark. */
 /* Builds and schedules the step program `which` ("miller", "millerfq", "miller2", "fe1", "fe2", "g2prep", "ell", "fq12mul",
  * "easy2", "hardgen", "inv1", "inv2", "conj", "frob0" .. "frob11", "pow:<16 hex digits per exponent word>") for groups of K lanes and copies it into

@@ -53,6 +53,7 @@ _sig("bls381_pairing_witness_kinds", C.c_int, u8p, C.c_size_t)
 _sig("bls381_pairing_witness_batch", C.c_int, ctxp, u64p, u64p, C.c_size_t, u32p)
 _sig("bls381_pairing_witness_batch_dev", C.c_int, ctxp, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 _sig("bls381_pairing_batch_dev", C.c_int, ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+_sig("bls381_pairing_batch_dev_noalloc", C.c_int, ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 _sig("bls381_miller_loop_batch_dev", C.c_int, ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 _sig("bls381_final_exp_batch_dev", C.c_int, ctxp, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
 _sig("bls381_g2_prepared_create", C.c_int, ctxp, u64p, C.c_int, C.POINTER(C.c_void_p))
@@ -91,7 +92,7 @@ EXPORTED = [
     "bls381_multi_pairing", "bls381_finish_multi_pairing", "bls381_g2_prepare_batch", "bls381_ell_batch",
     "bls381_easy_part_batch", "bls381_hard_part_batch", "bls381_frobenius_batch", "bls381_conjugate_batch", "bls381_pow_batch", "bls381_pow_x_batch", "bls381_fq12_mul_batch",
     "bls381_fq12_inverse_limbs_batch", "bls381_pairing_witness_rows", "bls381_pairing_witness_kinds",
-    "bls381_pairing_witness_batch", "bls381_pairing_witness_batch_dev", "bls381_pairing_batch_dev", "bls381_miller_loop_batch_dev",
+    "bls381_pairing_witness_batch", "bls381_pairing_witness_batch_dev", "bls381_pairing_batch_dev", "bls381_pairing_batch_dev_noalloc", "bls381_miller_loop_batch_dev",
     "bls381_final_exp_batch_dev", "bls381_g2_prepared_create", "bls381_g2_prepared_destroy",
     "bls381_fq_sqrt_limbs_batch", "bls381_fq2_sqrt_limbs_batch", "bls381_fq2_inverse_limbs_batch", "bls381_fq6_inverse_limbs_batch",
     "bls381_miller_loop_fixed_q_batch", "bls381_pairing_fixed_q_batch", "bls381_pairing_fixed_q_batch_dev", "bls381_debug_program", "bls381_debug_constants", "bls381_debug_profile", "bls381_debug_fp_mul", "bls381_debug_fp_inverse", "bls381_last_timing",

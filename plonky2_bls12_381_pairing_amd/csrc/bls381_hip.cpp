@@ -117,8 +117,15 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
+// Workspace of the entry point that allocates nothing (bls381_pairing_batch_dev_noalloc): every GPU the
+// library runs on holds its own copy of this array until the process ends.  Host code never uses the
+// array's name as an address: each context looks its device's copy up once (hipGetSymbolAddress).
+enum { NOALLOC_MAX_PAIRS = 4096, NOALLOC_SCRATCH_BYTES = 32 << 20 };
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
 struct bls381_ctx {
     int device = 0;
+    unsigned char* noalloc_scratch = nullptr;  // this device's copy of `scratch`
     int K = 8;
     int lds_slots = 0;
     bool auto_geometry = false;  // defaults requested: per-program lane-group width
@@ -256,6 +263,13 @@ extern "C" int bls381_ctx_create_ex(bls381_ctx** out, int device_id, int K, int 
     for (const char* nm : ALL_PROGRAMS) {
         rc = upload_program(c, nm);
         if (rc) return bail(rc);
+    }
+    {
+        void* sp = nullptr;
+        hipError_t e = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !sp)
+            return bail(fail(BLS381_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e)));
+        c->noalloc_scratch = (unsigned char*)sp;
     }
     *out = c;
     return 0;
@@ -521,6 +535,52 @@ extern "C" int bls381_miller_loop_batch_dev(bls381_ctx* c, const uint64_t* g1, c
     CTX_GUARD(c);
     if (n && (!g1 || !g2 || !out)) return fail(BLS381_ERR_INVALID, "NULL buffer");
     return miller_dev_locked(c, g1, g2, flags, n, out, false);
+}
+
+// bls381_pairing_batch_dev for callers that cannot allocate (code under graph capture, serving loops): the same
+// kernels, their workspace carved out of this device's copy of `scratch` instead of the context's growing buffers.
+// Calls nothing that allocates; at most NOALLOC_MAX_PAIRS pairs; always the context's own lane-group width (the
+// 16-lane program variants of small batches are uploaded on first use, which allocates).
+extern "C" int bls381_pairing_batch_dev_noalloc(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags,
+                                                size_t n, uint64_t* out) {
+    CTX_GUARD(c);
+    if (n == 0) return 0;
+    if (!g1 || !g2 || !out) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    if (n > NOALLOC_MAX_PAIRS)
+        return fail(BLS381_ERR_INVALID, "bls381_pairing_batch_dev_noalloc takes at most " + std::to_string((int)NOALLOC_MAX_PAIRS) +
+                                            " pairs per call (got " + std::to_string(n) + ")");
+    const int m = (int)n, npad = pad_elems(n);
+    const char* names[3] = {"miller", "fe1", "fe2"};
+    size_t tmp = 0;
+    for (const char* nm : names) {
+        auto it = c->progs.find(nm);
+        if (it == c->progs.end()) return fail(BLS381_ERR_INVALID, std::string("no program ") + nm);
+        tmp = std::max(tmp, spill_bytes(it->second, npad));
+    }
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t offA = 0, offB = offA + up(soa_bytes(6, npad)), offC = offB + up(soa_bytes(12, npad)),
+                 offT = offC + up(soa_bytes(FE_CARRY, npad)), need = offT + up(tmp);
+    if (need > (size_t)NOALLOC_SCRATCH_BYTES)
+        return fail(BLS381_ERR_INVALID, "this context's lane-group geometry needs a larger workspace than the fixed one (" +
+                                            std::to_string(need) + " > " + std::to_string((size_t)NOALLOC_SCRATCH_BYTES) + " bytes)");
+    unsigned char* ws = c->noalloc_scratch;  // (the device address; `scratch` itself is only a host-side handle)
+    void *bA = ws + offA, *bB = ws + offB, *bC = ws + offC, *bT = ws + offT;
+    int rc;
+    if ((rc = pack(c, g1, bA, m, npad, 2, 0))) return rc;
+    if ((rc = pack(c, g2, bA, m, npad, 4, 2))) return rc;
+    if ((rc = run_program_on(c, "miller", bA, bB, bT, m, npad))) return rc;
+    if (flags) {
+        hipLaunchKernelGGL(set_one_where_flag, dim3((m + 255) / 256), dim3(256), 0, c->stream, (uint4*)bB, flags, c->d_consts, m, npad);
+        HIPCHK(hipGetLastError());
+    }
+    if ((rc = run_program_on(c, "fe1", bB, bC, bT, m, npad))) return rc;
+    hipLaunchKernelGGL(fp_inverse_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, (uint4*)bC, 0, m, npad, c->d_consts,
+                       (uint8_t*)nullptr);
+    HIPCHK(hipGetLastError());
+    if ((rc = run_program_on(c, "fe2", bC, bB, bT, m, npad))) return rc;
+    if ((rc = unpack(c, bB, out, m, npad, 12, 0))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 // generic "n x in_fp Fp in -> program -> n x out_fp Fp out" on device pointers (up to 3 input arrays)
