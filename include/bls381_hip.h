@@ -170,7 +170,7 @@ int bls381_pairing_batch_dev_noalloc(bls381_ctx*, const uint64_t* g1_dev, const 
 /* Introspection used by the tests and the benchmark. */
 /* Builds and schedules the step program `which` ("miller", "millerfq", "miller2", "fe1", "fe2", "g2prep", "ell", "fq12mul",
  * "easy2", "hardgen", "inv1", "inv2", "conj", "frob0" .. "frob11", "pow:<16 hex digits per exponent word>") for groups of K lanes and copies it into
- * caller buffers: hdrs = nsteps x 2 u32, descs = nsteps x K x 8 u32.  info[8] receives
+ * caller buffers: hdrs = nsteps x 2 u32, descs = nsteps x K x 12 u32.  info[8] receives
  * {K, nsteps, lds_slots, tmp_slots, n_in, n_out, multiply-accumulates executed (300 per product, 444 per two-product sum), n_lin}.  Pass NULL buffers to query sizes.
  * Host-only: needs no GPU. */
 int bls381_debug_program(const char* which, int lanes_per_group, int lds_slots, uint32_t* hdrs, uint32_t* descs,

@@ -91,14 +91,19 @@ struct DevProgram {
     int nblocks = 0;
 };
 
-// 64 packed descriptors per block: step j of the block, lane-in-group r at index j * K + r
-static std::vector<PackedDesc> pack_blocks(const Program& p) {
+// 64 packed descriptors per block, as two planes of 64 x 16 bytes (words 0..3, then words 4..7): step j of the
+// block, lane-in-group r at index j * K + r of each plane
+static std::vector<uint32_t> pack_blocks(const Program& p) {
     const int K = p.K, spb = 64 / K, nsteps = (int)p.hdrs.size();
     const int nblocks = (nsteps + spb - 1) / spb;
-    std::vector<PackedDesc> out((size_t)std::max(1, nblocks) * 64, PackedDesc{{0, 0, 0, 0}});
+    std::vector<uint32_t> out((size_t)std::max(1, nblocks) * 512, 0u);
     for (int s = 0; s < nsteps; s++)
-        for (int r = 0; r < K; r++)
-            out[(size_t)(s / spb) * 64 + (s % spb) * K + r] = pack_desc(p.hdrs[s], p.descs[(size_t)s * K + r]);
+        for (int r = 0; r < K; r++) {
+            const PackedDesc d = pack_desc(p.hdrs[s], p.descs[(size_t)s * K + r]);
+            uint32_t* blk = &out[(size_t)(s / spb) * 512];
+            const int at = (s % spb) * K + r;
+            for (int w = 0; w < 4; w++) { blk[at * 4 + w] = d.w[w]; blk[256 + at * 4 + w] = d.w[4 + w]; }
+        }
     return out;
 }
 
@@ -172,17 +177,21 @@ static Program microbench_program(const std::string& which, int K, int slots) {
     StepHdr h{ST_COPY, 0};
     int nterms = 0;
     uint32_t kind = 0;
+    int width = 1;
     if (which.rfind("t_lin", 0) == 0) { h.type = ST_LIN; nterms = atoi(which.c_str() + 5); }
     else if (which.rfind("t_sweep", 0) == 0) { h.type = ST_LIN; nterms = atoi(which.c_str() + 7); h.max_terms = 1u << 8; }
     else if (which.rfind("t_reduce", 0) == 0) { h.type = ST_LIN; nterms = atoi(which.c_str() + 8); h.max_terms = 2u << 8; }
     else if (which == "t_mul") h.type = ST_FMUL;
     else if (which == "t_dot2") h.type = ST_DOT2;
+    else if (which == "t_dot2w2") { h.type = ST_DOT2; width = 2; }
+    else if (which == "t_dot2w3") { h.type = ST_DOT2; width = 3; }
     else if (which == "t_spill") kind = CK_SPILL;
     else if (which == "t_fill") kind = CK_FILL;
     else if (which == "t_const") kind = CK_CONST;
     else throw std::runtime_error("unknown program " + which);
     if (nterms < 0 || nterms > LIN_MAX_TERMS || slots < 3 * K + 2) throw std::runtime_error("bad microbenchmark " + which);
-    h.max_terms |= (uint32_t)nterms;
+    if (h.type == ST_LIN) h.max_terms |= (uint32_t)nterms;
+    if (h.type == ST_FMUL || h.type == ST_DOT2) h.max_terms = (uint32_t)width;
     for (int s = 0; s < 1000; s++) {
         p.hdrs.push_back(h);
         for (int r = 0; r < K; r++) {
@@ -193,9 +202,17 @@ static Program microbench_program(const std::string& which, int K, int slots) {
                 d.w[0] = (uint16_t)r; d.w[1] = (uint16_t)(kind == CK_CONST ? r % C_COUNT : r);
             } else {
                 d.w[0] = (uint16_t)(2 * K + r);
-                for (int t = 0; t < 8; t++) d.w[1 + t] = (uint16_t)((r + 3 * t + s) % (2 * K));
-                if (h.type == ST_DOT2) d.hdr |= 2u | (r & 1 ? 4u : 0u);
-                if (h.type == ST_LIN) { d.hdr |= (uint32_t)nterms << 8; if (nterms > 1) { d.w[2] |= 0x8000; d.hdr |= 1u << 24; } }
+                for (int t = 1; t <= 12; t++) d.w[t] = (uint16_t)(slots - 2);
+                if (h.type == ST_LIN) {
+                    d.hdr |= (uint32_t)nterms << 8;
+                    for (int t = 0; t < nterms; t++)
+                        d.w[1 + t] = (uint16_t)(((r + 3 * t + s) % (2 * K)) | (((t == 1 ? -1 : 1) & 0xff) << 7));
+                } else {
+                    for (int jo = 0; jo < (h.type == ST_DOT2 ? 4 : 2); jo++)
+                        for (int t = 0; t < width; t++)
+                            d.w[1 + 3 * jo + t] = (uint16_t)(((r + 3 * jo + 5 * t + s) % (2 * K)) | ((jo == 3 && (r & 1)) ? 0x8000 : 0));
+                    if (h.type == ST_DOT2) d.hdr |= 2u;
+                }
             }
             p.descs.push_back(d);
         }
@@ -214,10 +231,10 @@ static int upload_program(bls381_ctx* c, const std::string& which) {
         return fail(BLS381_ERR_INVALID, std::string("program ") + which + ": " + e.what());
     }
     if (dp.host.n_lds_slots > MAX_LDS_SLOTS) return fail(BLS381_ERR_INVALID, "more LDS slots than a descriptor can address");
-    std::vector<PackedDesc> blocks = pack_blocks(dp.host);
-    dp.nblocks = (int)(blocks.size() / 64);
-    HIPCHK(hipMalloc((void**)&dp.d_blocks, blocks.size() * sizeof(PackedDesc)));
-    hipError_t e = hipMemcpy(dp.d_blocks, blocks.data(), blocks.size() * sizeof(PackedDesc), hipMemcpyHostToDevice);
+    std::vector<uint32_t> blocks = pack_blocks(dp.host);
+    dp.nblocks = (int)(blocks.size() / 512);
+    HIPCHK(hipMalloc((void**)&dp.d_blocks, blocks.size() * 4));
+    hipError_t e = hipMemcpy(dp.d_blocks, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(dp.d_blocks);
         return fail(BLS381_ERR_HIP, std::string("program upload (") + which + "): " + hipGetErrorString(e));
@@ -1269,8 +1286,8 @@ extern "C" int bls381_debug_program(const char* which, int K, int lds_slots, uin
     info[0] = K; info[1] = (uint32_t)p.hdrs.size(); info[2] = p.n_lds_slots; info[3] = p.n_tmp_slots;
     info[4] = p.n_in; info[5] = p.n_out; info[6] = p.n_fmul * 300 + p.n_dot2 * 444; info[7] = p.n_lin;
     if (getenv("BLS381_SCHED_STATS"))
-        fprintf(stderr, "%s K=%d slots=%d: steps %zu (mul %d, dot2 %d, sum %d, copy %d) ops: mul %d dot2 %d sum %d (terms %d, reducing %d, sweeping %d) copy %d tmp %d\n",
-                which, K, lds_slots, p.hdrs.size(), p.n_fmul_steps, p.n_dot2_steps, p.n_lin_steps, p.n_copy_steps, p.n_fmul,
+        fprintf(stderr, "%s K=%d slots=%d: steps %zu (mul %d, dot2 %d [wide %d], sum %d, copy %d) ops: mul %d dot2 %d sum %d (terms %d, reducing %d, sweeping %d) copy %d tmp %d\n",
+                which, K, lds_slots, p.hdrs.size(), p.n_fmul_steps, p.n_dot2_steps, p.n_wide_mul_steps, p.n_lin_steps, p.n_copy_steps, p.n_fmul,
                 p.n_dot2, p.n_lin, p.n_lin_terms, p.n_reduce, p.n_norm, p.n_copy, p.n_tmp_slots);
     if (getenv("BLS381_SCHED_STATS")) fprintf(stderr, "   carried fills %d, carried spills %d\n", p.n_piggy_fill, p.n_piggy_spill);
     if (hdrs && descs) {

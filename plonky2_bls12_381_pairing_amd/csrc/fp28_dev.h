@@ -145,20 +145,74 @@ __device__ __forceinline__ void xor_add28_first(u32* acc, const u32* x, u32 m, u
           "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]), "v"(x[13]), "v"(m), "v"(c));
 }
 
-// Digits of magnitude up to 7 * 2^28, |value| below 2500 p  ->  normalised, value in (-0.2 p, 1.2 p):
-// subtracts q * p, q = an estimate of value / p from the top digit (the carries still owed to it
-// move it by at most 8, 1e-4 of p's top digit), then sweeps.
+// acc[i] = x[i] * k (first term of a sum) and acc[i] += x[i] * k: one v_mad_u64_u32 per digit.  Only the low
+// halves of the accumulators are digits (the product of a digit and a small signed coefficient taken
+// mod 2^32, exact while the sum stays inside 32 bits); the high halves are never read.
+__device__ __forceinline__ void coef_mul28(u64* acc, const u32* x, u32 k, u64 z0, u64 zm, u64 zt) {
+    // acc[i] = x[i] * k + z: z0 for digit 0, zm for digits 1..12, zt for the top digit
+    asm("v_mad_u64_u32 %0, vcc, %14, %28, %29\n\t"
+        "v_mad_u64_u32 %1, vcc, %15, %28, %30\n\t"
+        "v_mad_u64_u32 %2, vcc, %16, %28, %30\n\t"
+        "v_mad_u64_u32 %3, vcc, %17, %28, %30\n\t"
+        "v_mad_u64_u32 %4, vcc, %18, %28, %30\n\t"
+        "v_mad_u64_u32 %5, vcc, %19, %28, %30\n\t"
+        "v_mad_u64_u32 %6, vcc, %20, %28, %30\n\t"
+        "v_mad_u64_u32 %7, vcc, %21, %28, %30\n\t"
+        "v_mad_u64_u32 %8, vcc, %22, %28, %30\n\t"
+        "v_mad_u64_u32 %9, vcc, %23, %28, %30\n\t"
+        "v_mad_u64_u32 %10, vcc, %24, %28, %30\n\t"
+        "v_mad_u64_u32 %11, vcc, %25, %28, %30\n\t"
+        "v_mad_u64_u32 %12, vcc, %26, %28, %30\n\t"
+        "v_mad_u64_u32 %13, vcc, %27, %28, %31"
+        : "=&v"(acc[0]), "=&v"(acc[1]), "=&v"(acc[2]), "=&v"(acc[3]), "=&v"(acc[4]), "=&v"(acc[5]), "=&v"(acc[6]),
+          "=&v"(acc[7]), "=&v"(acc[8]), "=&v"(acc[9]), "=&v"(acc[10]), "=&v"(acc[11]), "=&v"(acc[12]), "=&v"(acc[13])
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]),
+          "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]), "v"(x[13]), "v"(k), "v"(z0), "v"(zm), "v"(zt)
+        : "vcc");
+}
+__device__ __forceinline__ void coef_mad28(u64* acc, const u32* x, u32 k) {
+    asm("v_mad_u64_u32 %0, vcc, %14, %28, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %15, %28, %1\n\t"
+        "v_mad_u64_u32 %2, vcc, %16, %28, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %17, %28, %3\n\t"
+        "v_mad_u64_u32 %4, vcc, %18, %28, %4\n\t"
+        "v_mad_u64_u32 %5, vcc, %19, %28, %5\n\t"
+        "v_mad_u64_u32 %6, vcc, %20, %28, %6\n\t"
+        "v_mad_u64_u32 %7, vcc, %21, %28, %7\n\t"
+        "v_mad_u64_u32 %8, vcc, %22, %28, %8\n\t"
+        "v_mad_u64_u32 %9, vcc, %23, %28, %9\n\t"
+        "v_mad_u64_u32 %10, vcc, %24, %28, %10\n\t"
+        "v_mad_u64_u32 %11, vcc, %25, %28, %11\n\t"
+        "v_mad_u64_u32 %12, vcc, %26, %28, %12\n\t"
+        "v_mad_u64_u32 %13, vcc, %27, %28, %13"
+        : "+&v"(acc[0]), "+&v"(acc[1]), "+&v"(acc[2]), "+&v"(acc[3]), "+&v"(acc[4]), "+&v"(acc[5]), "+&v"(acc[6]),
+          "+&v"(acc[7]), "+&v"(acc[8]), "+&v"(acc[9]), "+&v"(acc[10]), "+&v"(acc[11]), "+&v"(acc[12]), "+&v"(acc[13])
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]),
+          "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]), "v"(x[13]), "v"(k)
+        : "vcc");
+}
+
+// Digits in [-8 * (2^28 - 1), 7 * 2^28], |value| below 2500 p  ->  normalised, value in (-0.2 p, 1.2 p):
+// sweeps (after which the subtraction below cannot leave 32 bits), then subtracts q * p, q = an estimate of
+// value / p from the top digit, in a second sweep.
 __device__ __forceinline__ void reduce28(u32* d) {
     const u32 P[D28] = BLS381_P28_DIGITS;
+    normalise28(d);
     const int q = __mulhi((int)d[D28 - 1], 40323);  // floor(top * floor(2^32 / (top digit of p + 1)) / 2^32)
     int64_t c = 0;
+    int carry = 0;
 #pragma unroll
     for (int i = 0; i < D28; i++) {
         c += (int64_t)q * (int)P[i];
-        d[i] -= (i < D28 - 1) ? ((u32)c & BLS381_MASK28) : (u32)c;  // the top digit takes what is left, sign included
+        if (i < D28 - 1) {
+            const int t = (int)d[i] - (int)((u32)c & BLS381_MASK28) + carry;
+            d[i] = (u32)t & BLS381_MASK28;
+            carry = t >> 28;
+        } else {
+            d[i] = d[i] - (u32)c + (u32)carry;  // the top digit takes what is left, sign included
+        }
         c >>= 28;
     }
-    normalise28(d);
 }
 
 // Normalised value in (-p, 2p) -> [0, p)

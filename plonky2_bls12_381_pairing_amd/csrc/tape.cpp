@@ -14,6 +14,8 @@
 
 namespace bls381 {
 
+static int env_int(const char* nm, int dflt) { const char* v = getenv(nm); return v ? atoi(v) : dflt; }
+
 int Dag::load_in(int slot) {
     Node n; n.kind = NK_LOADIN; n.idx = slot;
     nodes.push_back(n);
@@ -26,18 +28,47 @@ int Dag::load_const(int cid) {
 }
 int Dag::fmul(int a, int b) {
     assert(a >= 0 && b >= 0);
-    Node n; n.kind = NK_FMUL; n.a = a; n.b = b;
+    Node n; n.kind = NK_FMUL; n.op[0] = {Term{a, 1}}; n.op[1] = {Term{b, 1}};
     nodes.push_back(n);
     return (int)nodes.size() - 1;
 }
 int Dag::dot2(int a, int b, int c, int d, bool neg_d) {
     assert(a >= 0 && b >= 0 && c >= 0 && d >= 0);
-    Node n; n.kind = NK_DOT2; n.a = a; n.b = b; n.c = c; n.d = d; n.neg_d = neg_d;
+    Node n; n.kind = NK_DOT2;
+    n.op[0] = {Term{a, 1}}; n.op[1] = {Term{b, 1}}; n.op[2] = {Term{c, 1}}; n.op[3] = {Term{d, neg_d ? -1 : 1}};
     nodes.push_back(n);
     return (int)nodes.size() - 1;
 }
+// equal nodes merge into one term, terms that cancel vanish
+static std::vector<Term> merge_terms(const std::vector<Term>& in) {
+    std::vector<Term> out;
+    for (auto& t : in) {
+        bool found = false;
+        for (auto& o : out) if (o.node == t.node) { o.coef += t.coef; found = true; break; }
+        if (!found) out.push_back(t);
+    }
+    std::vector<Term> nz;
+    for (auto& o : out) if (o.coef != 0) nz.push_back(o);
+    return nz;
+}
+// Digits are signed 32-bit numbers: a sum of normalised values (digits in [0, 2^28)) stays inside them while its
+// positive coefficients add up to at most 7 and its negative ones to at most 8, or, computed around a shifted
+// zero (see the scheduler's bound analysis), while both together add up to at most 15.
+static bool coefficients_fit(const std::vector<Term>& terms) {
+    int pos = 0, neg = 0;
+    for (auto& t : terms) {
+        if (std::abs(t.coef) > LIN_MAX_COEF) return false;
+        (t.coef > 0 ? pos : neg) += std::abs(t.coef);
+    }
+    static const bool use_bias = env_int("BLS381_LIN_BIAS", 1) != 0;
+    return use_bias ? pos + neg <= 15 : (pos <= 7 && neg <= 8);
+}
 int Dag::lin(std::vector<Term> terms) {
     assert(!terms.empty());
+    std::vector<Term> merged = merge_terms(terms);
+    // (x - x stays as written: a zero value is still a value; so does a sum whose merged coefficients would not
+    // fit a digit: the scheduler then sweeps its sources)
+    if (!merged.empty() && coefficients_fit(merged)) terms = merged;
     Node n; n.kind = NK_LIN; n.terms = std::move(terms);
     nodes.push_back(n);
     return (int)nodes.size() - 1;
@@ -48,45 +79,23 @@ void Dag::store_out(int node, int slot) {
     nodes.push_back(n);
 }
 
+static inline int n_operands(const Node& n) { return n.kind == NK_DOT2 ? 4 : (n.kind == NK_FMUL ? 2 : 0); }
+static inline bool is_mul(const Node& n) { return n.kind == NK_FMUL || n.kind == NK_DOT2; }
+
 static void for_each_src(const Node& n, const std::function<void(int)>& f) {
     switch (n.kind) {
-        case NK_FMUL: f(n.a); f(n.b); break;
-        case NK_DOT2: f(n.a); f(n.b); f(n.c); f(n.d); break;
+        case NK_FMUL:
+        case NK_DOT2:
+            for (int j = 0; j < n_operands(n); j++) for (auto& t : n.op[j]) f(t.node);
+            break;
         case NK_LIN: for (auto& t : n.terms) f(t.node); break;
         case NK_STOREOUT: f(n.a); break;
         default: break;
     }
 }
 
-void Dag::optimise() {
+static void drop_dead_nodes(std::vector<Node>& nodes) {
     const int n = (int)nodes.size();
-    std::vector<int> uses(n, 0);
-    for (auto& nd : nodes) for_each_src(nd, [&](int s) { uses[s]++; });
-    // inline single-use LINs into LIN consumers
-    for (int i = 0; i < n; i++) {
-        Node& nd = nodes[i];
-        if (nd.kind != NK_LIN) continue;
-        bool changed = true;
-        while (changed) {
-            changed = false;
-            for (size_t k = 0; k < nd.terms.size(); k++) {
-                Term t = nd.terms[k];
-                const Node& in = nodes[t.node];
-                if (in.kind != NK_LIN || uses[t.node] != 1) continue;
-                if (nd.terms.size() - 1 + in.terms.size() > (size_t)LIN_MAX_TERMS) continue;
-                std::vector<Term> nt;
-                for (size_t j = 0; j < nd.terms.size(); j++) {
-                    if (j != k) { nt.push_back(nd.terms[j]); continue; }
-                    for (auto& it : in.terms) nt.push_back(Term{it.node, it.neg != t.neg});
-                }
-                uses[t.node] = 0;
-                nd.terms = nt;
-                changed = true;
-                break;
-            }
-        }
-    }
-    // dead-code elimination
     std::vector<char> live(n, 0);
     for (int i = n - 1; i >= 0; i--) {
         if (nodes[i].kind == NK_STOREOUT) live[i] = 1;
@@ -97,14 +106,120 @@ void Dag::optimise() {
     for (int i = 0; i < n; i++) {
         if (!live[i]) continue;
         Node nd = nodes[i];
-        if (nd.kind == NK_FMUL) { nd.a = remap[nd.a]; nd.b = remap[nd.b]; }
-        else if (nd.kind == NK_DOT2) { nd.a = remap[nd.a]; nd.b = remap[nd.b]; nd.c = remap[nd.c]; nd.d = remap[nd.d]; }
-        else if (nd.kind == NK_STOREOUT) { nd.a = remap[nd.a]; }
-        else if (nd.kind == NK_LIN) for (auto& t : nd.terms) t.node = remap[t.node];
+        for (int j = 0; j < 4; j++) for (auto& t : nd.op[j]) t.node = remap[t.node];
+        for (auto& t : nd.terms) t.node = remap[t.node];
+        if (nd.kind == NK_STOREOUT) nd.a = remap[nd.a];
         remap[i] = (int)out.size();
         out.push_back(nd);
     }
     nodes.swap(out);
+}
+
+void Dag::optimise() {
+    // ---- 1. single-use sums move into the sums that consume them
+    {
+        const int n = (int)nodes.size();
+        std::vector<int> uses(n, 0);
+        for (auto& nd : nodes) for_each_src(nd, [&](int s) { uses[s]++; });
+        for (int i = 0; i < n; i++) {
+            Node& nd = nodes[i];
+            if (nd.kind != NK_LIN) continue;
+            bool changed = true;
+            while (changed) {
+                changed = false;
+                for (size_t k = 0; k < nd.terms.size(); k++) {
+                    const Term t = nd.terms[k];
+                    const Node& in = nodes[t.node];
+                    if (in.kind != NK_LIN || uses[t.node] != 1) continue;
+                    std::vector<Term> nt;
+                    for (size_t j = 0; j < nd.terms.size(); j++) {
+                        if (j != k) { nt.push_back(nd.terms[j]); continue; }
+                        for (auto& it : in.terms) nt.push_back(Term{it.node, it.coef * t.coef});
+                    }
+                    nt = merge_terms(nt);
+                    if (nt.empty() || nt.size() > (size_t)LIN_MAX_TERMS || !coefficients_fit(nt)) continue;
+                    uses[t.node] = 0;
+                    nd.terms = nt;
+                    changed = true;
+                    break;
+                }
+            }
+        }
+        drop_dead_nodes(nodes);
+    }
+    // ---- 2. short sums that only feed multiplications become part of those multiplications' operands:
+    // the multiplier adds them up in registers as it loads them.  A sum step costs every lane of the group
+    // some hundred instructions however short its sums are; a term added on the way into a multiplier
+    // costs about twenty.
+    const int max_terms = std::min((int)MUL_MAX_TERMS, env_int("BLS381_ABSORB_TERMS", MUL_MAX_TERMS));
+    const int max_uses2 = env_int("BLS381_ABSORB_USES2", 4), max_uses3 = env_int("BLS381_ABSORB_USES3", 2);
+    if (max_terms >= 1) {
+        const int n = (int)nodes.size();
+        std::vector<int> mul_uses(n, 0), other_uses(n, 0);
+        for (auto& nd : nodes) {
+            if (is_mul(nd)) for_each_src(nd, [&](int s) { mul_uses[s]++; });
+            else for_each_src(nd, [&](int s) { other_uses[s]++; });
+        }
+        // with every source normalised (digits in [0, 2^28)) an operand's digits stay below
+        // max(positive terms, negative terms) * 2^28: what the column accumulator has to hold
+        auto mag_of = [](const std::vector<Term>& op) {
+            int pos = 0, neg = 0;
+            for (auto& t : op) (t.coef > 0 ? pos : neg) += std::abs(t.coef);
+            return std::max(pos, neg);
+        };
+        std::vector<char> absorb(n, 0);
+        for (int i = 0; i < n; i++) {
+            const Node& L = nodes[i];
+            if (L.kind != NK_LIN || other_uses[i] != 0 || mul_uses[i] == 0) continue;
+            const int nt = (int)L.terms.size();
+            if (nt > max_terms) continue;
+            bool unit = true;
+            for (auto& t : L.terms) unit = unit && std::abs(t.coef) == 1;
+            if (!unit) continue;
+            if ((nt == 2 && mul_uses[i] > max_uses2) || (nt == 3 && mul_uses[i] > max_uses3)) continue;
+            absorb[i] = 1;
+        }
+        // a multiplication takes the sums it can hold: at most MUL_MAX_TERMS terms per operand, and the
+        // products' digit magnitudes within the accumulator's budget of 8
+        for (int i = 0; i < n; i++) {
+            Node& nd = nodes[i];
+            if (!is_mul(nd)) continue;
+            std::vector<Term> cand[4];
+            bool any = false;
+            for (int j = 0; j < n_operands(nd); j++) {
+                for (auto& t : nd.op[j]) {
+                    if (absorb[t.node]) { for (auto& it : nodes[t.node].terms) cand[j].push_back(Term{it.node, it.coef * t.coef}); any = true; }
+                    else cand[j].push_back(t);
+                }
+                cand[j] = merge_terms(cand[j]);
+            }
+            if (!any) continue;
+            bool ok = true;
+            int sd = 0;
+            for (int j = 0; j < n_operands(nd); j++) {
+                ok = ok && !cand[j].empty() && (int)cand[j].size() <= MUL_MAX_TERMS;
+                for (auto& t : cand[j]) ok = ok && std::abs(t.coef) == 1;
+            }
+            if (ok) for (int j = 0; j < n_operands(nd); j += 2) sd += mag_of(cand[j]) * mag_of(cand[j + 1]);
+            if (!ok || sd > 8) {
+                // this consumer keeps its operands as they are, so the sums must exist after all
+                for (int j = 0; j < n_operands(nd); j++) for (auto& t : nd.op[j]) absorb[t.node] = 0;
+            }
+        }
+        for (int i = 0; i < n; i++) {
+            Node& nd = nodes[i];
+            if (!is_mul(nd)) continue;
+            for (int j = 0; j < n_operands(nd); j++) {
+                std::vector<Term> nt;
+                for (auto& t : nd.op[j]) {
+                    if (absorb[t.node]) for (auto& it : nodes[t.node].terms) nt.push_back(Term{it.node, it.coef * t.coef});
+                    else nt.push_back(t);
+                }
+                nd.op[j] = merge_terms(nt);
+            }
+        }
+        drop_dead_nodes(nodes);
+    }
 }
 
 // ------------------------------------------------------------------------------- scheduler
@@ -155,21 +270,24 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
     }
 
     // ---- bound analysis.  Values are lazily reduced signed-digit numbers:
-    //   |value| < vb * p                 (value bound)
-    //   |digit| <= db * 2^28             (digit bound; the top digit follows from vb)
+    //   |value| < vb * p                          (value bound)
+    //   dlo * 2^28 <= digit <= dhi * 2^28         (digit interval of digits 0..12; the top digit follows from vb)
     //   product / two-product sum: result vb = 1 + ceil(sum of vb products / 2520)  (2^392 / p = 2520.2),
-    //                              db = 1; needs sum of db products <= 8  (64-bit column accumulator)
-    //   sum:                       vb and db add up; db <= 7 (32-bit digits)
-    //   sum + carry sweep:         db = 1
-    //   sum + sweep + reduction:   vb = 2, db = 1
+    //                              digits in [0, 1]; an operand is a signed sum of values, its digit magnitude
+    //                              the larger end of its interval; needs the sum over the products of
+    //                              magnitude(a) * magnitude(b) <= 8  (64-bit column accumulator)
+    //   sum:                       vb adds up, the interval follows the coefficients' signs; magnitude <= 7 (32-bit digits)
+    //   sum + carry sweep:         digits in [0, 1]
+    //   sum + sweep + reduction:   vb = 2, digits in [0, 1]
     // A sum gets a sweep or a reduction only when a consumer's limit demands it.
     // (a product of larger operands is still exact, its result is just wider: |result| <
     // (1 + sum / 2520) p.  The hard limits are the 28-bit top digit of an operand, vb <= 2047, and the
     // same for results.)
     const long MUL_VB_LIMIT = 2520L * 2046, MUL_DB_LIMIT = 8;
-    const int SUM_VB_LIMIT = 2047, SUM_DB_LIMIT = 7;
-    std::vector<int> vb(n, 1), db(n, 1);
+    const int SUM_VB_LIMIT = 2047, SUM_HI_LIMIT = 7, SUM_LO_LIMIT = -8;  // 7 * 2^28 and -8 * (2^28 - 1) are 32-bit digits
+    std::vector<int> vb(n, 1), dlo(n, 0), dhi(n, 1), dmag(n, 1);
     std::vector<char> lin_norm(n, 0), lin_reduce(n, 0);
+    std::vector<int> lin_bias(n, 0);  // sums whose digits only fit 32 bits around a shifted zero, see below
     int n_reduce = 0, n_norm = 0;
     // picks the sum among `cands` with the largest bound that has not been treated yet
     std::vector<char> narrow(n, 0);  // products whose result must stay below 2p: their own operands get reduced
@@ -177,10 +295,16 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         int best = -1;
         for (int x : cands) {
             const bool sum_ok = N[x].kind == NK_LIN && !done_flag[x] && !lin_reduce[x];
-            const bool mul_ok = (N[x].kind == NK_FMUL || N[x].kind == NK_DOT2) && !narrow[x] && bnd[x] > 2 && &bnd == &vb;
+            const bool mul_ok = is_mul(N[x]) && !narrow[x] && bnd[x] > 2 && &bnd == &vb;
             if ((sum_ok || mul_ok) && (best < 0 || bnd[x] > bnd[best])) best = x;
         }
-        if (best < 0) throw std::runtime_error("scheduler: operand bounds cannot be met (" + name + ")");
+        if (best < 0) {
+            std::string what;
+            for (int x : cands)
+                what += " [kind " + std::to_string((int)N[x].kind) + " vb " + std::to_string(vb[x]) + " digits " + std::to_string(dlo[x]) + ".." +
+                        std::to_string(dhi[x]) + (lin_norm[x] ? " swept" : "") + (lin_reduce[x] ? " reduced" : "") + "]";
+            throw std::runtime_error("scheduler: operand bounds cannot be met (" + name + "):" + what);
+        }
         return best;
     };
     // marks the chosen node: a sum gets the flag, a wide product is made narrow instead
@@ -190,8 +314,19 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
     };
     // Sums with several consumers are treated eagerly once their bounds pass a threshold: one sweep
     // or reduction there spares each consumer (and their consumers) its own.
-    auto env_int = [](const char* nm, int dflt) { const char* v = getenv(nm); return v ? atoi(v) : dflt; };
     const int VB_EAGER = env_int("BLS381_VB_EAGER", 400), DB_EAGER = env_int("BLS381_DB_EAGER", 3);
+    const bool use_bias = env_int("BLS381_LIN_BIAS", 1) != 0;
+    struct SumBound { long v; int lo, hi, mag; };
+    auto sum_bound = [&](const std::vector<Term>& terms) {
+        SumBound b{0, 0, 0, 0};
+        for (auto& t : terms) {
+            b.v += (long)std::abs(t.coef) * vb[t.node];
+            b.lo += t.coef > 0 ? t.coef * dlo[t.node] : t.coef * dhi[t.node];
+            b.hi += t.coef > 0 ? t.coef * dhi[t.node] : t.coef * dlo[t.node];
+        }
+        b.mag = std::max(-b.lo, b.hi);
+        return b;
+    };
     // One pass in node order; when node i asks for a treatment of an operand x, everything from x on is
     // recomputed (nothing before x depends on x's flags).
     {
@@ -200,44 +335,98 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
             int redo = -1;  // node whose flags changed
             auto treated = [&](int x, std::vector<char>& flag, int& counter) { treat(x, flag, counter); redo = x; };
             switch (nd.kind) {
-                case NK_LOADIN: vb[i] = 10; db[i] = 1; break;  // any 384-bit pattern is below 10p
-                case NK_LOADC: vb[i] = 1; db[i] = 1; break;
+                case NK_LOADIN: vb[i] = 10; dlo[i] = 0; dhi[i] = 1; break;  // any 384-bit pattern is below 10p
+                case NK_LOADC: vb[i] = 1; dlo[i] = 0; dhi[i] = 1; break;
                 case NK_FMUL:
                 case NK_DOT2: {
-                    std::vector<int> ops{nd.a, nd.b};
-                    long sv = (long)vb[nd.a] * vb[nd.b];
-                    int sd = db[nd.a] * db[nd.b];
-                    if (nd.kind == NK_DOT2) {
-                        ops.push_back(nd.c); ops.push_back(nd.d);
-                        sv += (long)vb[nd.c] * vb[nd.d]; sd += db[nd.c] * db[nd.d];
+                    std::vector<int> ops;
+                    long sv = 0;
+                    int sd = 0;
+                    bool operand_too_wide = false;
+                    for (int j = 0; j < n_operands(nd); j += 2) {
+                        const SumBound a = sum_bound(nd.op[j]), b = sum_bound(nd.op[j + 1]);
+                        sv += a.v * b.v;
+                        sd += a.mag * b.mag;
+                        operand_too_wide |= a.hi > SUM_HI_LIMIT || a.lo < SUM_LO_LIMIT || b.hi > SUM_HI_LIMIT || b.lo < SUM_LO_LIMIT;
                     }
-                    if (sv > (narrow[i] ? 2500L : MUL_VB_LIMIT)) treated(widest(ops, vb, lin_reduce), lin_reduce, n_reduce);
-                    else if (sd > MUL_DB_LIMIT) treated(widest(ops, db, lin_norm), lin_norm, n_norm);
-                    vb[i] = 1 + (int)((sv + 2519) / 2520); db[i] = 1;
+                    for (int j = 0; j < n_operands(nd); j++) for (auto& t : nd.op[j]) ops.push_back(t.node);
+                    bool vb_fail = sv > (narrow[i] ? 2500L : MUL_VB_LIMIT);
+                    for (int j = 0; j < n_operands(nd); j++) vb_fail |= sum_bound(nd.op[j]).v > SUM_VB_LIMIT;
+                    if (vb_fail) treated(widest(ops, vb, lin_reduce), lin_reduce, n_reduce);
+                    else if (sd > MUL_DB_LIMIT || operand_too_wide) treated(widest(ops, dmag, lin_norm), lin_norm, n_norm);
+                    vb[i] = 1 + (int)((sv + 2519) / 2520); dlo[i] = 0; dhi[i] = 1;
                     break;
                 }
                 case NK_LIN: {
-                    int sv = 0, sd = 0;
+                    const SumBound b = sum_bound(nd.terms);
                     std::vector<int> ops;
-                    for (auto& t : nd.terms) { sv += vb[t.node]; sd += db[t.node]; ops.push_back(t.node); }
-                    if (sv > SUM_VB_LIMIT) treated(widest(ops, vb, lin_reduce), lin_reduce, n_reduce);
-                    else if (sd > SUM_DB_LIMIT) treated(widest(ops, db, lin_norm), lin_norm, n_norm);
-                    else if (succ[i].size() >= 2) {
-                        if (sv >= VB_EAGER && !lin_reduce[i]) { lin_reduce[i] = 1; n_reduce++; }
-                        else if (sd >= DB_EAGER && !lin_norm[i] && !lin_reduce[i]) { lin_norm[i] = 1; n_norm++; }
+                    for (auto& t : nd.terms) ops.push_back(t.node);
+                    // A sum whose digit interval is no wider than 32 bits hold, but lopsided, is computed around a
+                    // shifted zero: the digit vector (B, B - B/2^28, ..., -B/2^28 on top) * 2^28 has the value 0, so
+                    // starting the accumulators from it moves every digit by B * 2^28 and changes nothing else.
+                    // Such a sum is swept right away.
+                    int bias = 0;
+                    bool fits = b.hi <= SUM_HI_LIMIT && b.lo >= SUM_LO_LIMIT;
+                    if (!fits && use_bias && b.hi - b.lo <= SUM_HI_LIMIT - SUM_LO_LIMIT) {
+                        bias = b.hi > SUM_HI_LIMIT ? SUM_HI_LIMIT - b.hi : SUM_LO_LIMIT - b.lo;
+                        fits = bias >= -8 && bias <= 7;
+                        if (!fits) bias = 0;
                     }
-                    vb[i] = lin_reduce[i] ? 2 : sv;
-                    db[i] = (lin_reduce[i] || lin_norm[i]) ? 1 : sd;
+                    if (b.v > SUM_VB_LIMIT) treated(widest(ops, vb, lin_reduce), lin_reduce, n_reduce);
+                    else if (!fits) treated(widest(ops, dmag, lin_norm), lin_norm, n_norm);
+                    else if (bias != 0) { if (!lin_norm[i] && !lin_reduce[i]) { lin_norm[i] = 1; n_norm++; } }
+                    else if (succ[i].size() >= 2) {
+                        if (b.v >= VB_EAGER && !lin_reduce[i]) { lin_reduce[i] = 1; n_reduce++; }
+                        else if (b.mag >= DB_EAGER && !lin_norm[i] && !lin_reduce[i]) { lin_norm[i] = 1; n_norm++; }
+                    }
+                    lin_bias[i] = bias;
+                    vb[i] = lin_reduce[i] ? 2 : (int)b.v;
+                    // (the sweep / reduction flags are per step: a sum that asks for neither may still get one from a
+                    // neighbour in its step, so its interval has to cover the normalised form as well)
+                    if (lin_reduce[i] || lin_norm[i]) { dlo[i] = 0; dhi[i] = 1; } else { dlo[i] = std::min(b.lo, 0); dhi[i] = std::max(b.hi, 1); }
                     break;
                 }
                 case NK_STOREOUT:
                     // a store handles (-p, 2p) with normalised digits: what multiplications produce
-                    if (N[nd.a].kind != NK_FMUL && N[nd.a].kind != NK_DOT2)
+                    if (!is_mul(N[nd.a]))
                         throw std::runtime_error("scheduler: stored value must come from a multiplication");
                     if (vb[nd.a] > 2 && !narrow[nd.a]) { narrow[nd.a] = 1; redo = nd.a; }
                     break;
             }
+            dmag[i] = std::max(-dlo[i], dhi[i]);
             i = redo >= 0 ? redo : i + 1;
+        }
+    }
+    if (const char* tn = getenv("BLS381_SCHED_NODE")) {
+        std::vector<int> todo{atoi(tn)};
+        for (int depth = 0; depth < 3; depth++) {
+            std::vector<int> nxt;
+            for (int x : todo) {
+                if (x < 0 || x >= n) continue;
+                fprintf(stderr, "node %d kind %d vb %d [%d..%d]%s%s bias %d:", x, (int)N[x].kind, vb[x], dlo[x], dhi[x], lin_norm[x] ? " swept" : "",
+                        lin_reduce[x] ? " reduced" : "", lin_bias[x]);
+                for (auto& t : N[x].terms) { fprintf(stderr, " %+d*n%d", t.coef, t.node); nxt.push_back(t.node); }
+                for (int j = 0; j < n_operands(N[x]); j++) { fprintf(stderr, " |"); for (auto& t : N[x].op[j]) fprintf(stderr, " %+d*n%d", t.coef, t.node); }
+                fprintf(stderr, "\n");
+            }
+            todo = nxt;
+        }
+    }
+    if (getenv("BLS381_SCHED_VERIFY")) {
+        for (int i = 0; i < n; i++) {
+            const Node& nd = N[i];
+            if (is_mul(nd)) {
+                int sd = 0;
+                for (int j = 0; j < n_operands(nd); j += 2) sd += sum_bound(nd.op[j]).mag * sum_bound(nd.op[j + 1]).mag;
+                if (sd > MUL_DB_LIMIT) fprintf(stderr, "verify: node %d product magnitudes %d\n", i, sd);
+            } else if (nd.kind == NK_LIN) {
+                const SumBound b = sum_bound(nd.terms);
+                const bool flagged = lin_norm[i] || lin_reduce[i];
+                if ((flagged ? 0 : std::min(b.lo, 0)) != dlo[i] || (flagged ? 1 : std::max(b.hi, 1)) != dhi[i])
+                    fprintf(stderr, "verify: sum %d interval %d..%d stored %d..%d flagged %d bias %d\n", i, b.lo, b.hi, dlo[i], dhi[i], (int)flagged, lin_bias[i]);
+                if (b.lo + lin_bias[i] < SUM_LO_LIMIT || b.hi + lin_bias[i] > SUM_HI_LIMIT)
+                    fprintf(stderr, "verify: sum %d interval %d..%d bias %d leaves a digit\n", i, b.lo, b.hi, lin_bias[i]);
+            }
         }
     }
     n_norm = 0;
@@ -245,10 +434,26 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
     for (int i = 0; i < n; i++) n_norm += lin_norm[i];
     P.n_reduce = n_reduce; P.n_norm = n_norm;
 
+    // how a multiplication's operands are laid out in its descriptor.  One term per operand with signs
+    // that fit "a * b + c * (+-d)" (products swapped if need be) runs on the short path; anything else
+    // takes the path that adds up signed terms.
+    struct MulShape { int width; bool swap; };
+    auto mul_shape = [&](const Node& nd) {
+        MulShape sh{1, false};
+        for (int j = 0; j < n_operands(nd); j++) sh.width = std::max(sh.width, (int)nd.op[j].size());
+        if (sh.width > 1) return sh;
+        const int s1 = nd.op[0][0].coef * nd.op[1][0].coef;
+        const int s2 = nd.kind == NK_DOT2 ? nd.op[2][0].coef * nd.op[3][0].coef : 1;
+        if (s1 > 0) return sh;
+        if (nd.kind == NK_DOT2 && s2 > 0) { sh.swap = true; return sh; }
+        sh.width = 2;  // both products negative: needs the signed path
+        return sh;
+    };
+
     // ---- pass 1: list scheduling into K-wide single-class steps
-    auto env_int2 = [](const char* nm, int dflt) { const char* v = getenv(nm); return v ? atoi(v) : dflt; };
-    const int WINDOW = env_int2("BLS381_WINDOW", 600);
-    const bool split_mul = env_int2("BLS381_SPLIT_MUL", 0) != 0;
+    const int WINDOW = env_int("BLS381_WINDOW", 600);
+    const bool split_mul = env_int("BLS381_SPLIT_MUL", 0) != 0;
+    const bool group_wide = env_int("BLS381_GROUP_WIDE", 1) != 0;
     std::vector<char> done(n, 0);
     std::vector<int> ready;  // nodes whose predecessors all sit in closed steps
     int lo = 0, n_done = 0;
@@ -282,11 +487,19 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
             if ((int)doubles.size() >= K) c.swap(doubles);
             else if ((int)singles.size() >= K) c.swap(singles);
         }
+        if ((int)c.size() > K && cls == OC_FMUL && group_wide) {
+            // operands of several terms make the whole step take the long load path: keep the most urgent
+            // op and fill the step with ops of its kind first
+            const int lead_w = mul_shape(N[c[0]]).width;
+            std::stable_sort(c.begin() + 1, c.end(), [&](int a, int b) {
+                return std::abs(mul_shape(N[a]).width - lead_w) < std::abs(mul_shape(N[b]).width - lead_w);
+            });
+        }
         if ((int)c.size() > K) {
             if (cls == OC_LIN) {
                 // keep the most urgent op, fill the step with the ops closest to it in cost
                 int lead = c[0];
-                auto cost = [&](int x) { return (int)N[x].terms.size() * 20 + lin_norm[x] * 40 + lin_reduce[x] * 100; };
+                auto cost = [&](int x) { return (int)N[x].terms.size() * 22 + lin_norm[x] * 40 + lin_reduce[x] * 100; };
                 std::stable_sort(c.begin() + 1, c.end(), [&](int a, int b) {
                     return std::abs(cost(a) - cost(lead)) < std::abs(cost(b) - cost(lead));
                 });
@@ -418,7 +631,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                 if (for_fill) {
                     if (carrier_prev && !from_prev && prev_nspill < K && t < 128) {  // 7-bit fields in the packed descriptor
                         OpDesc& d = P.descs[prev_idx * K + prev_nspill++];
-                        d.w[11] = (uint16_t)(victim | 0x8000); d.w[12] = (uint16_t)t;
+                        d.w[DW_SPILL] = (uint16_t)(victim | 0x8000); d.w[DW_SPILL + 1] = (uint16_t)t;
                         prev_spilled.insert(t);
                         P.hdrs[prev_idx].max_terms |= 1u << 17;
                         P.n_piggy_spill++;
@@ -452,7 +665,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
             const bool aliases = f.kind == CK_FILL && prev_spilled.count(f.src);
             if (carrier_prev && how != 2 && prev_nfill < K && f.src < 1024 && !aliases) {
                 OpDesc& d = P.descs[prev_idx * K + prev_nfill++];
-                d.w[9] = (uint16_t)(sl | 0x8000); d.w[10] = (uint16_t)(f.src | ((uint32_t)f.kind << 12));
+                d.w[DW_FILL] = (uint16_t)(sl | 0x8000); d.w[DW_FILL + 1] = (uint16_t)(f.src | ((uint32_t)f.kind << 12));
                 P.hdrs[prev_idx].max_terms |= 1u << 16;
                 P.n_piggy_fill++;
             } else {
@@ -489,17 +702,22 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         StepHdr h; h.max_terms = 0;
         int step_rounds = 0;
         bool any_dot2 = false;
-        for (int op : st.ops) any_dot2 |= (N[op].kind == NK_DOT2);
+        int mul_width = 1;
+        for (int op : st.ops) {
+            any_dot2 |= (N[op].kind == NK_DOT2);
+            if (is_mul(N[op])) mul_width = std::max(mul_width, mul_shape(N[op]).width);
+        }
         // a step holding a two-product op runs the two-product multiplier on every lane; single
         // products in it use zero for the second product
         h.type = st.cls == OC_FMUL ? (any_dot2 ? ST_DOT2 : ST_FMUL) : (st.cls == OC_LIN ? ST_LIN : ST_COPY);
+        if (st.cls == OC_FMUL) h.max_terms = (uint32_t)mul_width;
         for (int r = 0; r < K; r++) {
             OpDesc d; std::memset(&d, 0, sizeof d);
             if (st.cls != OC_COPY) {  // idle lane / padding defaults
                 d.w[0] = (uint16_t)TRASH_SLOT;
-                for (int t = 1; t <= 8; t++) d.w[t] = (uint16_t)ZERO_SLOT;
+                for (int t = 1; t <= 12; t++) d.w[t] = (uint16_t)ZERO_SLOT;
                 if (r < (int)cur_spills.size()) {
-                    d.w[11] = (uint16_t)(cur_spills[r].first | 0x8000); d.w[12] = (uint16_t)cur_spills[r].second;
+                    d.w[DW_SPILL] = (uint16_t)(cur_spills[r].first | 0x8000); d.w[DW_SPILL + 1] = (uint16_t)cur_spills[r].second;
                     P.n_piggy_spill++;
                 }
             }
@@ -509,26 +727,44 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                 d.hdr = 1u;
                 switch (nd.kind) {
                     case NK_FMUL:
-                        d.w[0] = (uint16_t)dst_slot[op]; d.w[1] = (uint16_t)src_slot[nd.a]; d.w[2] = (uint16_t)src_slot[nd.b];
-                        P.n_fmul++;
+                    case NK_DOT2: {
+                        const MulShape sh = mul_shape(nd);
+                        if (getenv("BLS381_SCHED_TRACE") && atoi(getenv("BLS381_SCHED_TRACE")) == (int)P.hdrs.size()) {
+                            fprintf(stderr, "step %zu lane %d node %d:", P.hdrs.size(), r, op);
+                            for (int j = 0; j < n_operands(nd); j++) {
+                                fprintf(stderr, " op%d{", j);
+                                for (auto& t : nd.op[j])
+                                    fprintf(stderr, " %+d*n%d(kind %d [%d..%d]%s%s slot %d)", t.coef, t.node, (int)N[t.node].kind, dlo[t.node], dhi[t.node],
+                                            lin_norm[t.node] ? " swept" : "", lin_reduce[t.node] ? " reduced" : "", src_slot[t.node]);
+                                fprintf(stderr, " }");
+                            }
+                            fprintf(stderr, "\n");
+                        }
+                        if (nd.kind == NK_DOT2) { d.hdr |= 2u; P.n_dot2++; } else P.n_fmul++;
+                        d.w[0] = (uint16_t)dst_slot[op];
+                        for (int j = 0; j < n_operands(nd); j++) {
+                            const std::vector<Term>& terms = nd.op[sh.swap ? (j ^ 2) : j];
+                            // on the short path the sign of each product sits on its second factor, and only
+                            // d's is looked at: a * b + c * (+-d)
+                            const int prod_sign = terms[0].coef * nd.op[(sh.swap ? (j ^ 2) : j) ^ 1][0].coef;
+                            for (size_t t = 0; t < terms.size(); t++) {
+                                bool neg = terms[t].coef < 0;
+                                if (mul_width == 1) neg = (j & 1) && prod_sign < 0;
+                                d.w[1 + 3 * j + t] = (uint16_t)(src_slot[terms[t].node] | (neg ? 0x8000 : 0));
+                            }
+                        }
                         break;
-                    case NK_DOT2:
-                        d.hdr |= 2u;  // second product present
-                        if (nd.neg_d) d.hdr |= 4u;  // subtract it
-                        d.w[0] = (uint16_t)dst_slot[op]; d.w[1] = (uint16_t)src_slot[nd.a]; d.w[2] = (uint16_t)src_slot[nd.b];
-                        d.w[3] = (uint16_t)src_slot[nd.c]; d.w[4] = (uint16_t)src_slot[nd.d];
-                        P.n_dot2++;
-                        break;
+                    }
                     case NK_LIN: {
                         int nt = (int)nd.terms.size();
                         assert(nt <= LIN_MAX_TERMS);
                         d.hdr |= (uint32_t)nt << 8;
+                        d.hdr |= ((uint32_t)lin_bias[op] & 0xfu) << 24;
                         d.w[0] = (uint16_t)dst_slot[op];
-                        for (int t = 0; t < nt; t++)
-                            d.w[1 + t] = (uint16_t)(src_slot[nd.terms[t].node] | (nd.terms[t].neg ? 0x8000 : 0));
-                        int nneg = 0;
-                        for (auto& t : nd.terms) nneg += t.neg;
-                        d.hdr |= (uint32_t)nneg << 24;
+                        for (int t = 0; t < nt; t++) {
+                            assert(nd.terms[t].coef != 0 && std::abs(nd.terms[t].coef) <= LIN_MAX_COEF);
+                            d.w[1 + t] = (uint16_t)(src_slot[nd.terms[t].node] | (((uint32_t)nd.terms[t].coef & 0xffu) << 7));
+                        }
                         h.max_terms = std::max<uint32_t>(h.max_terms, nt);
                         step_rounds |= (lin_reduce[op] ? 2 : 0) | (lin_norm[op] ? 1 : 0);
                         P.n_lin++; P.n_lin_terms += nt;
@@ -557,6 +793,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         prev_nfill = 0; prev_nspill = (int)cur_spills.size();
         prev_spilled.clear();
         for (auto& cs : cur_spills) prev_spilled.insert(cs.second);
+        if (st.cls == OC_FMUL && mul_width > 1) P.n_wide_mul_steps++;
         if (st.cls == OC_FMUL && any_dot2) P.n_dot2_steps++;
         else if (st.cls == OC_FMUL) P.n_fmul_steps++;
         else if (st.cls == OC_LIN) P.n_lin_steps++;

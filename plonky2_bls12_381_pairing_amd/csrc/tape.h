@@ -16,16 +16,17 @@ enum NodeKind : uint8_t { NK_FMUL, NK_LIN, NK_LOADIN, NK_LOADC, NK_STOREOUT, NK_
 
 struct Term {
     int node;
-    bool neg;
+    int coef;  // small signed integer, never zero (operands of multiplications: +1 or -1)
 };
 
 struct Node {
     NodeKind kind;
-    int a = -1, b = -1;       // FMUL / DOT2 operands; STOREOUT source in a
-    int c = -1, d = -1;       // DOT2: a*b + c*d
-    bool neg_d = false;       // DOT2: a*b - c*d (the kernel forms k*p - d)
+    // FMUL: op[0] * op[1]; DOT2: op[0] * op[1] + op[2] * op[3].  Every operand is a signed sum of up to
+    // MUL_MAX_TERMS values: one term as built, more once optimise() has folded an operand's sum into it.
+    std::vector<Term> op[4];
+    int a = -1;               // STOREOUT source
     int idx = -1;             // LOADIN: gin slot, LOADC: constant id, STOREOUT: gout slot
-    std::vector<Term> terms;  // LIN
+    std::vector<Term> terms;  // LIN: sum of coef * node
 };
 
 class Dag {
@@ -36,12 +37,13 @@ class Dag {
     int load_in(int slot);
     int load_const(int cid);
     int fmul(int a, int b);
-    int dot2(int a, int b, int c, int d, bool neg_d = false);
+    int dot2(int a, int b, int c, int d, bool neg_d = false);  // a*b + c*d, or a*b - c*d
     int lin(std::vector<Term> terms);
     void store_out(int node, int slot);
 
-    // Inlines single-use LIN nodes into their LIN consumers (bounded by LIN_MAX_TERMS),
-    // cancels x - x, and drops nodes nothing depends on.
+    // Inlines single-use sums into the sums that consume them (coefficients multiply, equal terms merge),
+    // folds short sums that only feed multiplications into those multiplications' operands, and drops
+    // nodes nothing depends on.
     void optimise();
 };
 
@@ -58,6 +60,7 @@ struct Program {
     int n_fmul_steps = 0, n_lin_steps = 0, n_copy_steps = 0, n_dot2_steps = 0;
     int n_piggy_fill = 0, n_piggy_spill = 0;  // copies riding on compute steps
     int n_reduce = 0, n_norm = 0;  // sums followed by a reduction / by a carry sweep only
+    int n_wide_mul_steps = 0;      // multiplier steps with more than one term in some operand
 };
 
 // Schedules `dag` for groups of K lanes with at most `lds_slots` LDS slots per group.

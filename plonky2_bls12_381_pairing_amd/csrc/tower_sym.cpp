@@ -20,10 +20,10 @@ SFp Tower::lin(const std::vector<std::pair<SFp, int>>& terms) {
     for (auto& p : terms) {
         if (p.first.is_zero()) continue;
         SFp m = mat(p.first);
-        t.push_back(Term{m.id, p.second < 0});
+        t.push_back(Term{m.id, p.second});
     }
     if (t.empty()) return SZERO;
-    if (t.size() == 1 && !t[0].neg) return SFp{t[0].node};
+    if (t.size() == 1 && t[0].coef == 1) return SFp{t[0].node};
     return SFp{d_.lin(t)};
 }
 SFp Tower::lin(std::initializer_list<std::pair<SFp, int>> terms) {
@@ -41,7 +41,7 @@ static int materialise_for_store(Dag& d, Tower& T, SFp a) {
     if (a.is_zero()) {
         // 0 = 1 - 1 keeps the store path uniform
         SFp one = T.cst(C_ONE);
-        return d.lin({Term{one.id, false}, Term{one.id, true}});
+        return d.lin({Term{one.id, 1}, Term{one.id, -1}});
     }
     return a.is_one() ? T.cst(C_ONE).id : a.id;
 }
@@ -161,10 +161,12 @@ SFq12 Tower::mul_by_014(const SFq12& f, const SFq2& c0, const SFq2& c1, const SF
 SFq12 Tower::cyclotomic_sqr(const SFq12& a) {
     const SFq2 &r0 = a.c0.c0, &r4 = a.c0.c1, &r3 = a.c0.c2, &r2 = a.c1.c0, &r1 = a.c1.c1, &r5 = a.c1.c2;
     auto fq4_sqr = [&](const SFq2& x, const SFq2& y, SFq2& t_even, SFq2& t_odd) {
-        // (x + y s)^2 with s^2 = xi:  t_even = x^2 + xi y^2,  t_odd = 2xy
+        // (x + y s)^2 with s^2 = xi:  t_even = x^2 + xi y^2 = (x - y)(x - xi y) + (1 + xi) xy,  t_odd = 2xy.
+        // The differences (rather than (x + y)(x + xi y) - (1 + xi) xy) keep the digits of the factors within
+        // [-2, 2] * 2^28, so the multiplier can take them as sums of slots with no carry sweep in between.
         SFq2 xy = mul(x, y);
-        SFq2 t = mul(add(x, y), add(mul_xi(y), x));
-        t_even = sub(sub(t, xy), mul_xi(xy));
+        SFq2 t = mul(sub(x, y), sub(x, mul_xi(y)));
+        t_even = add(add(t, xy), mul_xi(xy));
         t_odd = add(xy, xy);
     };
     SFq2 t0, t1, t2, t3, t4, t5;

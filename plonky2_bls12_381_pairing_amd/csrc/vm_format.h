@@ -14,10 +14,10 @@
 namespace bls381 {
 
 enum StepType : uint32_t {
-    ST_FMUL = 0,  // dst = a * b / 2^392              (in (-p, 2p), digits normalised)
-    ST_LIN  = 1,  // dst = sum_i (+/-) t_i            (digit-wise, no carries unless a step flag asks)
+    ST_FMUL = 0,  // dst = a * b / 2^392              (in (-p, 2p), digits normalised); a, b: signed sums of up to 3 slots
+    ST_LIN  = 1,  // dst = sum_i k_i * t_i            (digit-wise, small integer k_i, no carries unless a step flag asks)
     ST_COPY = 2,  // LDS <-> global slot arrays, constant table -> LDS
-    ST_DOT2 = 3,  // dst = (a * b +/- c * d) / 2^392  (one Montgomery reduction, in (-p, 2p))
+    ST_DOT2 = 3,  // dst = (a * b + c * d) / 2^392    (one Montgomery reduction, in (-p, 2p)); operands as for ST_FMUL
 };
 
 enum CopyKind : uint32_t {
@@ -30,76 +30,95 @@ enum CopyKind : uint32_t {
 
 struct StepHdr {
     uint32_t type;       // StepType
-    uint32_t max_terms;  // ST_LIN: bits 0..7 largest term count among the step's ops,
-                         //         bit 8: results get a carry sweep (digits back below 2^28)
+    uint32_t max_terms;  // bits 0..7: ST_LIN: largest term count among the step's ops (<= 7);
+                         //            multiplier steps: largest number of terms in any operand (1..3)
+                         // ST_LIN: bit 8: results get a carry sweep (digits back below 2^28)
                          //         bit 9: results are also brought into (-0.2p, 1.2p): quotient
                          //                estimate from the top digit
                          // multiplier and sum steps: bit 16 some lane carries a fill, bit 17 a spill
 };
 
-// One operation descriptor per (step, lane-in-group).  32 bytes.
+// One operation descriptor per (step, lane-in-group).  48 bytes.
 //   hdr bit 0      : active
 //   hdr bit 1      : ST_DOT2: the op has a second product (else dst = a * b)
-//   hdr bit 2      : ST_DOT2: the second product is subtracted
 //   Idle lanes of multiplier and sum steps carry dst = TRASH slot and operands = ZERO slot (the
 //   program's last two LDS slots), so those steps run without per-lane branches.
 //   hdr bits 8..15 : ST_LIN term count / ST_COPY CopyKind
-//   hdr bits 24..31: ST_LIN number of negated terms
+//   hdr bits 24..27: ST_LIN: the sum starts from a shifted zero: every digit moves by B * 2^28, B this signed 4-bit
+//                    number (the digit vector added has the value 0); the step sweeps
 //   w[0]           : destination slot
-//   ST_FMUL        : w[1] = a, w[2] = b
-//   ST_DOT2        : w[1] = a, w[2] = b, w[3] = c, w[4] = d
-//   ST_LIN         : w[1+i] = slot | (negate << 15), i < term count <= 7
+//   ST_FMUL, ST_DOT2: every operand is a signed sum of up to three slots; term t of operand j (a, b, c, d = 0..3)
+//                    is w[1 + 3 j + t] = slot | (negate << 15), missing terms are the ZERO slot.  The result is
+//                    a * b (+ c * d): a difference of products is expressed through the signs of d's terms.  In a
+//                    step whose header says one term per operand only d's sign is honoured.
+//   ST_LIN         : w[1 + i] = slot | ((coefficient & 0xff) << 7), i < term count <= 7; coefficients are
+//                    signed 8-bit integers, never zero
 //   ST_COPY        : w[1] = source slot (LDS slot, global slot or constant id)
 //   Multiplier and sum steps may carry copies besides their operation:
-//   w[9], w[10]    : fill: w[9] = LDS slot | 0x8000 (valid), w[10] = source slot | CopyKind << 12
+//   w[13], w[14]   : fill: w[13] = LDS slot | 0x8000 (valid), w[14] = source slot | CopyKind << 12
 //                    (CK_IN, CK_FILL or CK_CONST); the loads are issued as the step starts, the LDS
 //                    slot is written after the step's results
-//   w[11], w[12]   : spill: w[11] = LDS slot | 0x8000 (valid), w[12] = spill-array slot; read and
+//   w[15], w[16]   : spill: w[15] = LDS slot | 0x8000 (valid), w[16] = spill-array slot; read and
 //                    stored as the step starts, before the step's fills are issued
 struct OpDesc {
     uint32_t hdr;
-    uint16_t w[14];
+    uint16_t w[22];
 };
-static_assert(sizeof(OpDesc) == 32, "OpDesc must be 32 bytes");
+static_assert(sizeof(OpDesc) == 48, "OpDesc must be 48 bytes");
+enum { OPDESC_U32 = 12, DW_FILL = 13, DW_SPILL = 15 };
 
-enum { LIN_MAX_TERMS = 7, MAX_LDS_SLOTS = 128 };  // seven 2^28-bounded digits and their carries fit 32 bits
+enum { LIN_MAX_TERMS = 7, MUL_MAX_TERMS = 3, LIN_MAX_COEF = 127, MAX_LDS_SLOTS = 128 };
 
-// ---- device encoding.  The interpreter reads 16-byte descriptors, 64 per 1 KiB block: a block
-// holds floor(64 / K) consecutive steps, the descriptor of (step j of the block, lane-in-group r)
-// sits at index j * K + r, so one 16-byte load per lane fetches a whole block for a wave and the
-// lanes then pick their descriptors out of each other's registers.  The step-wide fields are
-// replicated into every descriptor of the step:
-//   w[0] bit 0 active, bit 1 second product, bit 2 subtract it, bits 3..4 StepType,
-//        bits 5..7 largest term count of the step, bits 8..9 sweep / reduce flags of the step,
-//        bits 10..12 CopyKind, bits 13..15 negated-term count, bits 16..31 destination slot
+// ---- device encoding.  The interpreter reads 32-byte descriptors, 64 per 2 KiB block, as two planes of
+// 64 x 16 bytes (words 0..3 of every descriptor, then words 4..7): a block holds floor(64 / K)
+// consecutive steps, the descriptor of (step j of the block, lane-in-group r) sits at index j * K + r,
+// so two 16-byte loads per lane fetch a whole block for a wave and the lanes then pick their
+// descriptors out of each other's registers.  The step-wide fields are replicated into every
+// descriptor of the step:
+//   w[0] bit 0 active, bit 1 second product, bit 2 unused, bits 3..4 StepType,
+//        bits 5..7 the step's largest term count (sums: terms of an op; multiplier steps: terms of an operand;
+//        copy steps: the CopyKind), bits 8..9 sweep / reduce flags of the step,
+//        bit 10 the step reads w[3], bit 11 the step reads w[4], sums: bits 12..15 the shifted zero B (signed),
+//        bits 16..31 destination slot
 //        (multiplier and sum steps: destination in bits 16..22, bit 23 some lane of the step
 //        carries a fill, bit 24 some lane carries a spill)
-//   w[1], w[2]  multiplier and sum steps: operand i in byte i, LDS slot in bits 0..6, negate in bit 7;
-//               copy steps: w[1] = source slot
-//   w[3]        carried copies: bits 0..6 fill LDS slot, 7..8 CopyKind, 9..18 source slot, 19 valid;
-//               bits 20..26 spill LDS slot, 27 valid; the spill-array slot sits in w[0] bits 25..31
+//   multiplier steps: w[1 + t], t = 0..2: term t of the operands a, b, c, d in bytes 0..3: LDS slot in bits 0..6,
+//        negate in bit 7
+//   sum steps: w[1 + i / 2], half i % 2: term i: LDS slot in bits 0..6, coefficient in bits 7..14
+//   copy steps: w[1] = source slot
+//   w[5] carried copies: bits 0..6 fill LDS slot, 7..8 CopyKind, 9..18 source slot, 19 valid;
+//        bits 20..26 spill LDS slot, 27 valid; the spill-array slot sits in w[0] bits 25..31
 struct PackedDesc {
-    uint32_t w[4];
+    uint32_t w[8];
 };
 inline PackedDesc pack_desc(const StepHdr& h, const OpDesc& d) {
-    PackedDesc p{{0, 0, 0, 0}};
+    PackedDesc p{{0, 0, 0, 0, 0, 0, 0, 0}};
     const uint32_t nterms_step = h.max_terms & 0xffu, flags = (h.max_terms >> 8) & 3u;
-    p.w[0] = (d.hdr & 7u) | (h.type << 3) | (nterms_step << 5) | (flags << 8) | ((uint32_t)d.w[0] << 16);
+    p.w[0] = (d.hdr & 3u) | (h.type << 3) | (nterms_step << 5) | (flags << 8) | ((uint32_t)d.w[0] << 16);
     if (h.type == ST_COPY) {
-        p.w[0] |= ((d.hdr >> 8) & 7u) << 10;
+        p.w[0] |= ((d.hdr >> 8) & 7u) << 5;  // (the term-count field is the copy kind here)
         p.w[1] = d.w[1];
     } else {
-        p.w[0] |= ((d.hdr >> 24) & 7u) << 13;
+        // which of the words beyond w[2] the step's lanes have to fetch
+        if (h.type == ST_LIN ? nterms_step > 4 : nterms_step > 2) p.w[0] |= 1u << 10;
+        if (h.type == ST_LIN && nterms_step > 6) p.w[0] |= 1u << 11;
         p.w[0] |= ((h.max_terms >> 16) & 3u) << 23;
-        for (int i = 0; i < 8; i++) {
-            const uint32_t b = (d.w[1 + i] & 0x7fu) | ((d.w[1 + i] & 0x8000u) ? 0x80u : 0u);
-            p.w[1 + i / 4] |= b << (8 * (i % 4));
+        if (h.type == ST_LIN) {
+            const uint32_t B = (d.hdr >> 24) & 0xfu;
+            p.w[0] |= B << 12;
+            for (int i = 0; i < LIN_MAX_TERMS; i++) p.w[1 + i / 2] |= (uint32_t)(d.w[1 + i] & 0x7fffu) << (16 * (i % 2));
+        } else {
+            for (int j = 0; j < 4; j++)
+                for (int t = 0; t < MUL_MAX_TERMS; t++) {
+                    const uint16_t e = d.w[1 + 3 * j + t];
+                    p.w[1 + t] |= (uint32_t)((e & 0x7fu) | ((e & 0x8000u) ? 0x80u : 0u)) << (8 * j);
+                }
         }
-        if (d.w[9] & 0x8000u)
-            p.w[3] |= (d.w[9] & 0x7fu) | (((d.w[10] >> 12) & 3u) << 7) | ((d.w[10] & 0x3ffu) << 9) | (1u << 19);
-        if (d.w[11] & 0x8000u) {
-            p.w[3] |= ((d.w[11] & 0x7fu) << 20) | (1u << 27);
-            p.w[0] |= (d.w[12] & 0x7fu) << 25;
+        if (d.w[DW_FILL] & 0x8000u)
+            p.w[5] |= (d.w[DW_FILL] & 0x7fu) | (((d.w[DW_FILL + 1] >> 12) & 3u) << 7) | ((d.w[DW_FILL + 1] & 0x3ffu) << 9) | (1u << 19);
+        if (d.w[DW_SPILL] & 0x8000u) {
+            p.w[5] |= ((d.w[DW_SPILL] & 0x7fu) << 20) | (1u << 27);
+            p.w[0] |= (d.w[DW_SPILL + 1] & 0x7fu) << 25;
         }
     }
     return p;

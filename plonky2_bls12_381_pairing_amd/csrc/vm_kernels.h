@@ -34,6 +34,7 @@ struct VmArgs {
 };
 
 enum { VM_THREADS = 256 };
+typedef const unsigned long long __attribute__((address_space(1))) * global_u64_ptr;
 
 __device__ __forceinline__ void unpack3(const uint4& a, const uint4& b, const uint4& c, u32* x) {
     x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
@@ -50,7 +51,7 @@ __host__ __device__ inline size_t vm_lds_bytes(int lds_slots, int K) {
 // TAG only gives the Miller-loop, final-exponentiation and auxiliary launches distinct kernel
 // names in profiler output; the code is identical.  TAG_PROFILE additionally has the first lane of
 // the grid add the shader-clock cycles of every step to A.prof, by step kind: 0 product, 1 sum,
-// 2 sum + carry sweep, 3 two-product, 4 + CopyKind copies, 9 sum + reduction.
+// 2 sum + carry sweep, 3 two-product, 4 + CopyKind copies, 9 sum + reduction, 10 multiplier step with summed operands.
 enum { TAG_MILLER = 0, TAG_FINAL_EXP = 1, TAG_AUX = 2, TAG_PROFILE = 3 };
 
 template <int K, int TAG>
@@ -90,15 +91,15 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
         p[2 * GPW] = make_uint4(x[8], x[9], x[10], x[11]);
         lds_tail[(size_t)slot * GPW + g] = make_uint2(x[12], x[13]);
     };
-    // One 16-byte load per lane fetches the descriptors of a block of SPB steps; two blocks are
-    // kept ahead of the one being executed, so no step waits on descriptor memory.
+    // Two 16-byte loads per lane fetch the descriptors of a block of SPB steps (words 0..3 and words 4..7 of
+    // each); two blocks are kept ahead of the one being executed, so no step waits on descriptor memory.
     constexpr int SPB = 64 / K;
     const uint4* bptr = A.blocks + lane;
     // (loads past the last block are clamped to it rather than skipped: a conditional load would
     // become a flat load, which LDS waits cannot tell apart from LDS traffic)
     const int last_block = A.nblocks - 1;
-    uint4 cur = bptr[0];
-    uint4 nxt = bptr[(size_t)min(1, last_block) * 64];
+    uint4 cur = bptr[0], cur_hi = bptr[64];
+    uint4 nxt = bptr[(size_t)min(1, last_block) * 128], nxt_hi = bptr[(size_t)min(1, last_block) * 128 + 64];
     long long t_prev = 0;
     int k_prev = -1;
     int s = 0;
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
     u32 ny = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)cur.y);
     u32 nz = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)cur.z);
     for (int b = 0; b < A.nblocks; b++) {
-      const uint4 ahead = bptr[(size_t)min(b + 2, last_block) * 64];
+      const uint4 ahead = bptr[(size_t)min(b + 2, last_block) * 128];
+      const uint4 ahead_hi = bptr[(size_t)min(b + 2, last_block) * 128 + 64];
       const int nj = min((int)SPB, A.nsteps - s);  // steps of this block
       for (int j = 0; j < nj; j++, s++) {
         const u32 dx = nx, dy = ny, dz = nz;
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             ny = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)nxt.y);
             nz = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)nxt.z);
         }
+        const int self = (j * K + role) * 4;
         const u32 hx = (u32)__builtin_amdgcn_readfirstlane((int)dx);  // step-wide fields
         const u32 type = (hx >> 3) & 3u, max_terms = (hx >> 5) & 7u, flags = (hx >> 8) & 3u;
         if (TAG == TAG_PROFILE && tid == 0 && blockIdx.x == 0) {
@@ -132,11 +135,11 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                 atomicAdd(A.prof + 16 + k_prev, 1ull);
             }
             t_prev = now;
-            k_prev = type == ST_COPY ? 4 + (int)((hx >> 10) & 7u) : (type == ST_LIN ? (flags & 2u ? 9 : (flags ? 2 : 1)) : (int)type);
+            k_prev = type == ST_COPY ? 4 + (int)max_terms
+                                     : (type == ST_LIN ? (flags & 2u ? 9 : (flags ? 2 : 1)) : (max_terms > 1 ? 10 : (int)type));
         }
         const bool on = lane_on && (dx & 1u);
         const u32 dst = type == ST_COPY ? dx >> 16 : (dx >> 16) & 0x7fu;
-        auto OP = [&](int i) -> u32 { return ((i < 4 ? dy : dz) >> ((i & 3) * 8)) & 0xffu; };
 
         // Copies carried by a multiplier or sum step.  Fill: the loads are issued now and land in LDS
         // after the step's results, their latency behind the step's arithmetic.  Spill: LDS slot ->
@@ -146,8 +149,14 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                       // the loaded registers, and so wait for the loads, right where they are issued
         u32 dw = 0;   // the descriptor word of the carried copies, fetched only by steps that carry any
         const bool carries = type != ST_COPY && (hx & (3u << 23));  // (a copy step's destination field extends over these bits)
+        // Descriptor words beyond the first three are fetched here, before the step issues any load from global
+        // memory: the block's registers came from global loads themselves, and a wait for them placed after the
+        // carried fills' loads would wait for those too.
+        u32 d3 = 0, d4 = 0;  // sums: terms 4..6; multiplier steps: the operands' third terms
+        if (hx & (1u << 10)) d3 = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur.w);
+        if (hx & (1u << 11)) d4 = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur_hi.x);
         if (carries) {
-            dw = (u32)__builtin_amdgcn_ds_bpermute((j * K + role) * 4, (int)cur.w);
+            dw = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur_hi.y);
             asm volatile("" : "+v"(dw));  // nothing derived from dw is computed (and waited for) by steps that carry nothing
         }
         if (carries && (hx & (1u << 23))) {
@@ -160,9 +169,12 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                     uint4 v0 = p[0], v1 = p[1], v2 = p[2];
                     // 8 bytes, not 16: registers a load writes but nothing reads get reused at once, and
                     // the reuse then has to wait for the load
-                    const uint2* pt = reinterpret_cast<const uint2*>(p + 3);
+                    // (a pointer known to be global memory: laundered as a generic pointer the load would be a flat
+                    // load, which counts as LDS traffic too and makes every later wait a wait for everything)
+                    global_u64_ptr pt = (global_u64_ptr)(p + 3);
                     asm volatile("" : "+v"(pt));  // keeps the compiler from widening the load again
-                    uint2 v3 = *pt;
+                    const unsigned long long t3 = *pt;
+                    const uint2 v3 = make_uint2((u32)t3, (u32)(t3 >> 32));
                     unpack3(v0, v1, v2, pf);
                     pf[12] = v3.x; pf[13] = v3.y;
                 } else {
@@ -191,28 +203,32 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
         }
         // Multiplier and sum steps are branch-free: idle lanes read the ZERO slot and store to TRASH.
         if (type == ST_LIN) {  // most frequent first
-            // acc = sum of (x ^ m), m = -1 for negated terms: each of those is one short of -x, which
-            // the first term makes up for by starting from the count of negated terms.  The loads
-            // of up to four terms are issued together so their latencies overlap.
-            u32 acc[D28];
-            const u32 nneg = (dx >> 13) & 7u;
+            // acc = sum of k * x over the op's terms, k a signed 8-bit coefficient: one multiply-add per digit
+            // (64-bit accumulators whose low halves are the digits; the high halves mean nothing).  The loads
+            // of up to four terms are issued together so their latencies overlap.  Sums shorter than the
+            // step's longest are padded with 0 * ZERO.
+            u64 acc[D28];
+            auto TERM = [&](int i) -> u32 { return ((i < 2 ? dy : (i < 4 ? dz : (i < 6 ? d3 : d4))) >> ((i & 1) * 16)) & 0x7fffu; };
+            // the shifted zero the sum starts from: B * 2^28 on digit 0, B * 2^28 - B on digits 1..12, -B on top
+            const int B = (int)(dx << 16) >> 28;  // bits 12..15, signed
+            const u64 z0 = (u32)(B << 28), zm = (u32)((B << 28) - B), zt = (u32)(-B);
             auto terms = [&](auto first_tag, auto count_tag) {
                 constexpr int T0 = decltype(first_tag)::value, N = decltype(count_tag)::value;
-                u32 x[N][D28], m[N];
+                u32 x[N][D28], k[N];
 #pragma unroll
                 for (int t = 0; t < N; t++) {
-                    const u32 w = OP(T0 + t);
-                    m[t] = (w & 0x80u) ? 0xffffffffu : 0u;
+                    const u32 w = TERM(T0 + t);
+                    k[t] = (u32)((int)(w << 17) >> 24);  // bits 7..14, sign-extended
                     lds_load(w & 0x7fu, x[t]);
                 }
 #pragma unroll
                 for (int t = 0; t < N; t++) {
-                    if (T0 + t == 0) xor_add28_first(acc, x[t], m[t], nneg);
-                    else xor_add28(acc, x[t], m[t]);
+                    if (T0 + t == 0) coef_mul28(acc, x[t], k[t], z0, zm, zt);
+                    else coef_mad28(acc, x[t], k[t]);
                 }
             };
 #define BLS381_IC(n) std::integral_constant<int, n>()
-            switch (max_terms) {  // uniform; short sums are padded with +ZERO
+            switch (max_terms) {  // uniform
                 case 1: terms(BLS381_IC(0), BLS381_IC(1)); break;
                 case 2: terms(BLS381_IC(0), BLS381_IC(2)); break;
                 case 3: terms(BLS381_IC(0), BLS381_IC(3)); break;
@@ -222,32 +238,69 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                 default: terms(BLS381_IC(0), BLS381_IC(4)); terms(BLS381_IC(4), BLS381_IC(3)); break;
             }
 #undef BLS381_IC
-            if (flags & 2u) reduce28(acc);  // sweeps as well
-            else if (flags) normalise28(acc);
-            lds_store(dst, acc);
-        } else if (type == ST_DOT2) {
-            u32 a[D28], b[D28], c[D28], d[D28], r[D28];
-            lds_load(OP(0), a);
-            lds_load(OP(1), b);
-            lds_load(OP(2), c);
-            lds_load(OP(3), d);
-            {
-                // a*b - c*d: negate d digit by digit, -d = (d ^ -1) + 1
-                const u32 m = (dx & 4u) ? 0xffffffffu : 0u;
-                const u32 one = m & 1u;
+            u32 r[D28];
 #pragma unroll
-                for (int i = 0; i < D28; i++) d[i] = (d[i] ^ m) + one;
-            }
-            fp28_dot2(a, b, c, d, r);
+            for (int i = 0; i < D28; i++) r[i] = (u32)acc[i];
+            if (flags & 2u) reduce28(r);  // sweeps as well
+            else if (flags) normalise28(r);
             lds_store(dst, r);
-        } else if (type == ST_FMUL) {
+        } else if (type == ST_DOT2 || type == ST_FMUL) {
+            // operands: a, b (, c, d), each a signed sum of up to max_terms slots added up as they are loaded
+            auto BYTE = [&](u32 word, int jop) -> u32 { return (word >> (jop * 8)) & 0xffu; };
+            auto operand = [&](int jop, u32* v) {
+                const u32 e0 = BYTE(dy, jop), e1 = BYTE(dz, jop);
+                const u32 m0 = (u32)((int)(e0 << 24) >> 31), m1 = (u32)((int)(e1 << 24) >> 31);
+                u32 x0[D28], x1[D28];
+                lds_load(e0 & 0x7fu, x0);
+                lds_load(e1 & 0x7fu, x1);
+                if (max_terms == 2) {
+                    // (x ^ m) is one short of -x for a negated term: the first term starts from their count
+                    xor_add28_first(v, x0, m0, 0u - (m0 + m1));
+                    xor_add28(v, x1, m1);
+                } else {
+                    const u32 e2 = BYTE(d3, jop);
+                    const u32 m2 = (u32)((int)(e2 << 24) >> 31);
+                    u32 x2[D28];
+                    lds_load(e2 & 0x7fu, x2);
+                    xor_add28_first(v, x0, m0, 0u - (m0 + m1 + m2));
+                    xor_add28(v, x1, m1);
+                    xor_add28(v, x2, m2);
+                }
+            };
             u32 a[D28], b[D28], r[D28];
-            lds_load(OP(0), a);
-            lds_load(OP(1), b);
-            fp28_mul(a, b, r);
+            if (type == ST_DOT2) {
+                u32 c[D28], d[D28];
+                if (max_terms <= 1) {  // uniform: plain operands, only d may be negated
+                    lds_load(BYTE(dy, 0) & 0x7fu, a);
+                    lds_load(BYTE(dy, 1) & 0x7fu, b);
+                    lds_load(BYTE(dy, 2) & 0x7fu, c);
+                    lds_load(BYTE(dy, 3) & 0x7fu, d);
+                    // a*b - c*d: negate d digit by digit, -d = (d ^ -1) + 1
+                    const u32 m = (u32)((int)dy >> 31);  // the sign bit of d's byte
+                    u32 nd[D28];
+                    xor_add28_first(nd, d, m, m & 1u);
+#pragma unroll
+                    for (int i = 0; i < D28; i++) d[i] = nd[i];
+                } else {
+                    operand(0, a);
+                    operand(1, b);
+                    operand(2, c);
+                    operand(3, d);
+                }
+                fp28_dot2(a, b, c, d, r);
+            } else {
+                if (max_terms <= 1) {
+                    lds_load(BYTE(dy, 0) & 0x7fu, a);
+                    lds_load(BYTE(dy, 1) & 0x7fu, b);
+                } else {
+                    operand(0, a);
+                    operand(1, b);
+                }
+                fp28_mul(a, b, r);
+            }
             lds_store(dst, r);
         } else {  // ST_COPY: every lane reads before any lane writes
-            const u32 kind = (dx >> 10) & 7u;
+            const u32 kind = (dx >> 5) & 7u;
             const u32 src = dy;
             // A fill may read what an earlier spill of this wave wrote (spills themselves are not
             // waited for): drain the wave's stores first.
@@ -271,9 +324,10 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                 } else if (kind == CK_CONST) {
                     const uint4* p = A.consts + (size_t)src * 4;
                     uint4 v0 = p[0], v1 = p[1], v2 = p[2];
-                    const uint2* pt = reinterpret_cast<const uint2*>(p + 3);
+                    global_u64_ptr pt = (global_u64_ptr)(p + 3);
                     asm volatile("" : "+v"(pt));
-                    uint2 v3 = *pt;
+                    const unsigned long long t3 = *pt;
+                    const uint2 v3 = make_uint2((u32)t3, (u32)(t3 >> 32));
                     unpack3(v0, v1, v2, v);
                     v[12] = v3.x; v[13] = v3.y;
                 } else {
@@ -320,8 +374,8 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             }
         }
       }
-      cur = nxt;
-      nxt = ahead;
+      cur = nxt; cur_hi = nxt_hi;
+      nxt = ahead; nxt_hi = ahead_hi;
     }
     if (TAG == TAG_PROFILE && tid == 0 && blockIdx.x == 0 && k_prev >= 0) {
         atomicAdd(A.prof + k_prev, (unsigned long long)(clock64() - t_prev));

@@ -19,6 +19,10 @@ MUL_LIMIT = (1 << RBITS) // P     # 2520: operand-bound products a multiplicatio
 ST_FMUL, ST_LIN, ST_COPY, ST_DOT2 = 0, 1, 2, 3
 CK_IN, CK_FILL, CK_CONST, CK_SPILL, CK_OUT = range(5)
 N_CONST = 21
+DEBUG = bool(os.environ.get('VM_SIM_DEBUG'))
+PROV = {}
+TPROV = {}
+DW = 12                           # 32-bit words per host-side descriptor (OpDesc: hdr + 22 half-words)
 
 
 def get_program(which, K=8, lds_slots=0):
@@ -26,7 +30,7 @@ def get_program(which, K=8, lds_slots=0):
     _lib.check(_lib.lib.bls381_debug_program(which.encode(), K, lds_slots, None, None, 0, info))
     nsteps = info[1]
     hdrs = (C.c_uint32 * (2 * nsteps))()
-    descs = (C.c_uint32 * (8 * nsteps * K))()
+    descs = (C.c_uint32 * (DW * nsteps * K))()
     _lib.check(_lib.lib.bls381_debug_program(which.encode(), K, lds_slots, hdrs, descs, nsteps, info))
     return dict(K=K, nsteps=nsteps, lds_slots=info[2], tmp_slots=info[3], n_in=info[4], n_out=info[5],
                 n_fmul=info[6], n_lin=info[7], hdrs=list(hdrs), descs=list(descs))
@@ -122,14 +126,20 @@ def normalise(d):
 
 
 def reduce(d):
-    d = list(d)
+    d = normalise(d)
     q = (d[13] * 40323) >> 32
     c = 0
+    carry = 0
     for i in range(14):
         c += q * P28[i]
-        d[i] = s32(d[i] - (c & MASK if i < 13 else c))   # the top digit takes what is left, sign included
+        if i < 13:
+            t = s32(d[i] - (c & MASK) + carry)
+            d[i] = t & MASK
+            carry = t >> 28
+        else:
+            d[i] = s32(d[i] - c + carry)             # the top digit takes what is left, sign included
         c >>= 28
-    return normalise(d)
+    return d
 
 
 def canon(d):
@@ -154,15 +164,14 @@ def run_program(prog, gin, strict=True, extra_consts=()):
         writes = []
         late = []                                   # carried fills: LDS written after the step's results
         if typ != ST_COPY:
-            carried = [(ds[(s * K + r) * 8 + 5], ds[(s * K + r) * 8 + 6], ds[(s * K + r) * 8 + 7]) for r in range(K)]
-            # w[9] = low half of dword 5 ... the descriptor dwords are hdr, w0|w1<<16, w2|w3<<16, ...
+            halves = lambda r: [h for x in ds[(s * K + r) * DW + 1:(s * K + r + 1) * DW] for h in (x & 0xffff, x >> 16)]
+            carried = [halves(r)[13:17] for r in range(K)]     # w[13], w[14] fill; w[15], w[16] spill
             any_fill = any_spill = False
             stored = set()
-            for d5, d6, d7 in carried:               # the fills' loads first
-                w9, w10 = d5 >> 16, d6 & 0xffff
-                if w9 & 0x8000:
+            for w13, w14, w15, w16 in carried:               # the fills' loads first
+                if w13 & 0x8000:
                     any_fill = True
-                    kind, src = w10 >> 12, w10 & 0xfff
+                    kind, src = w14 >> 12, w14 & 0xfff
                     assert src < 1024
                     if kind == CK_IN:
                         val = to_digits(gin[src])
@@ -172,61 +181,84 @@ def run_program(prog, gin, strict=True, extra_consts=()):
                     else:
                         assert kind == CK_CONST
                         val = consts[src]
-                    late.append((w9 & 0x7fff, val))
-            for d5, d6, d7 in carried:               # then the spills: LDS as the step finds it
-                w11, w12 = d6 >> 16, d7 & 0xffff
-                if w11 & 0x8000:
+                    late.append((w13 & 0x7fff, val))
+                    if DEBUG and os.environ.get('VM_SIM_DEBUG') == "fill%d" % s:
+                        print("step", s, "fill to slot", w13 & 0x7fff, "kind", kind, "src", src, "min/max digit %.2f %.2f" % (min(val) / 2 ** 28, max(val) / 2 ** 28), "tmp written", TPROV.get(src) if kind == CK_FILL else None)
+            for w13, w14, w15, w16 in carried:               # then the spills: LDS as the step finds it
+                if w15 & 0x8000:
                     any_spill = True
-                    assert lds[w11 & 0x7fff] is not None and w12 < 128
-                    assert w12 not in stored, "a step fills what it spills"
-                    gtmp[w12] = lds[w11 & 0x7fff]
+                    assert lds[w15 & 0x7fff] is not None and w16 < 128
+                    assert w16 not in stored, "a step fills what it spills"
+                    gtmp[w16] = lds[w15 & 0x7fff]
+                    TPROV[w16] = (s, "carried", w15 & 0x7fff, PROV.get(w15 & 0x7fff))
             assert bool(mt & 0x10000) == any_fill and bool(mt & 0x20000) == any_spill, "step-wide carry flags are wrong"
+        zero_slot = prog["lds_slots"] - 2
         for r in range(K):
-            d = ds[(s * K + r) * 8:(s * K + r) * 8 + 8]
-            if not (d[0] & 1):
-                if typ != ST_COPY:  # idle lanes run branch-free on ZERO and store to TRASH
-                    assert d[1] & 0xffff == prog["lds_slots"] - 1
-                    zero = prog["lds_slots"] - 2
-                    assert all(x == zero * 0x10001 for x in d[2:5]) and d[1] >> 16 == zero and d[5] & 0xffff == zero
-                continue
+            d = ds[(s * K + r) * DW:(s * K + r + 1) * DW]
             w = []
             for x in d[1:]:
                 w += [x & 0xffff, x >> 16]
-            if typ == ST_FMUL:
-                a, b = lds[w[1]], lds[w[2]]
-                assert a is not None and b is not None, "FMUL reads an empty slot"
-                assert abs(value(a)) < 2048 * P and abs(value(b)) < 2048 * P, "FMUL operand too wide"
-                out = mulacc(a, b)
-                assert (value(out) << RBITS) % P == value(a) * value(b) % P and abs(value(out)) < 2048 * P
-                writes.append(("lds", w[0], out))
-            elif typ == ST_DOT2:
-                a, b = lds[w[1]], lds[w[2]]
-                c2, d2 = lds[w[3]], lds[w[4]]
-                assert None not in (a, b, c2, d2), "DOT2 reads an empty slot"
-                if not d[0] & 2:
-                    assert value(c2) == 0 and value(d2) == 0          # single product: padded with ZERO
-                if d[0] & 4:
-                    d2 = [s32(-x) for x in d2]
-                t = value(a) * value(b) + value(c2) * value(d2)
-                assert all(abs(value(x)) < 2048 * P for x in (a, b, c2, d2)), "DOT2 operand too wide"
-                out = mulacc(a, b, c2, d2)
+            if not (d[0] & 1):
+                if typ != ST_COPY:  # idle lanes run branch-free on ZERO and store to TRASH
+                    assert w[0] == prog["lds_slots"] - 1 and all(x == zero_slot for x in w[1:13])
+                continue
+            if typ in (ST_FMUL, ST_DOT2):
+                width = mt & 0xff
+                assert 1 <= width <= 3
+                nops = 4 if typ == ST_DOT2 else 2
+
+                def operand(j):
+                    """Signed sum of the operand's terms, as the multiplier forms it in registers."""
+                    acc = [0] * 14
+                    for t in range(3):
+                        e = w[1 + 3 * j + t]
+                        v = lds[e & 0x7fff]
+                        assert v is not None, "multiplier reads an empty slot"
+                        if t >= width:
+                            assert e == zero_slot, "term beyond the step's operand width"
+                            continue
+                        neg = bool(e & 0x8000)
+                        if width == 1 and j != 3:
+                            assert not neg, "the short path only looks at d's sign"
+                        acc = [s32(x - y if neg else x + y) for x, y in zip(acc, v)]
+                    return acc
+                ops = [operand(j) for j in range(nops)]
+                if DEBUG:
+                    worst = sum(max(abs(x) for x in ops[2 * q]) * max(abs(x) for x in ops[2 * q + 1]) for q in range(nops // 2))
+                    if 14 * worst + 14 * MASK * MASK + (1 << 36) >= 1 << 63:
+                        print("step", s, "lane", r, "width", width, "terms", [hex(x) for x in w[1:13]])
+                        for j in range(nops):
+                            for t in range(width):
+                                e = w[1 + 3 * j + t]
+                                print("  op", j, "term", t, "slot", e & 0x7f, "neg", bool(e & 0x8000), "written by", PROV.get(e & 0x7f), "max digit %.2f" % (max(abs(x) for x in lds[e & 0x7f]) / 2 ** 28))
+                if typ == ST_DOT2 and not d[0] & 2:
+                    assert value(ops[2]) == 0 and value(ops[3]) == 0      # single product: padded with ZERO
+                assert all(abs(value(x)) < 2048 * P for x in ops), "multiplier operand too wide"
+                t = value(ops[0]) * value(ops[1]) + (value(ops[2]) * value(ops[3]) if nops == 4 else 0)
+                out = mulacc(*ops)
                 assert (value(out) << RBITS) % P == t % P and abs(value(out)) < 2048 * P
                 writes.append(("lds", w[0], out))
             elif typ == ST_LIN:
                 nt = (d[0] >> 8) & 0xff
-                nneg = d[0] >> 24
                 assert nt <= (mt & 0xff) <= 7
-                acc = [0] * 14
-                negs = 0
+                B = (d[0] >> 24) & 0xf
+                B -= 16 if B >= 8 else 0
+                assert B == 0 or mt & 0x300, "a sum around a shifted zero must be swept"
+                acc = [B << 28] + [(B << 28) - B] * 12 + [-B]        # a digit vector of value 0
+                assert value(acc) == 0
                 for t in range(mt & 0xff):
-                    v = lds[w[1 + t] & 0x7fff]
+                    e = w[1 + t]
+                    v = lds[e & 0x7f]
                     assert v is not None, "LIN reads an empty slot"
+                    coef = (e >> 7) & 0xff
+                    coef -= 256 if coef >= 128 else 0
                     if t >= nt:
-                        assert value(v) == 0 and not w[1 + t] & 0x8000
-                    sign = -1 if w[1 + t] & 0x8000 else 1
-                    negs += sign < 0
-                    acc = [s32(x + sign * y) for x, y in zip(acc, v)]
-                assert negs == nneg, "negated-term count in the descriptor is wrong"
+                        assert e == zero_slot               # padding: ZERO with coefficient 0
+                        continue
+                    assert coef != 0
+                    acc = [s32(x + coef * y) for x, y in zip(acc, v)]
+                if DEBUG and os.environ.get('VM_SIM_DEBUG') == "%d:%d" % (s, w[0]):
+                    print("LIN step", s, "dst", w[0], "mt", hex(mt), "terms", [(w[1 + t] & 0x7f, ((w[1 + t] >> 7) & 0xff), PROV.get(w[1 + t] & 0x7f), "%.2f" % (max(abs(x) for x in lds[w[1 + t] & 0x7f]) / 2 ** 28)) for t in range(nt)])
                 assert abs(value(acc)) < MUL_LIMIT * P
                 if mt & 0x200:
                     acc = reduce(acc)                # sweeps as well
@@ -258,8 +290,11 @@ def run_program(prog, gin, strict=True, extra_consts=()):
             seen.add((where, idx))
             if where == "lds":
                 lds[idx] = v
+                if DEBUG:
+                    PROV[idx] = (s, typ, hex(mt))
             elif where == "tmp":
                 gtmp[idx] = v
+                TPROV[idx] = (s, "copy step")
             else:
                 gout[idx] = v
     return gout
