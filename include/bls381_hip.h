@@ -155,6 +155,36 @@ int bls381_miller_loop_batch_dev(bls381_ctx*, const uint64_t* g1_dev, const uint
 int bls381_final_exp_batch_dev(bls381_ctx*, const uint64_t* in_fq12_dev, size_t n, uint64_t* out_fq12_dev,
                                uint8_t* is_zero_err_dev);
 
+/* ---- several GPUs behind one handle ------------------------------------------------------------
+ * The reference is single-threaded host code with no device notion (/root/reference/src/native/miller_loop.rs:139 runs
+ * its chunks sequentially); a drop-in for a multi-GPU node keeps one call per batch and lets the library spread it.
+ * bls381_multi_ctx_create builds one context per entry of device_ids (an id may be listed more than once: its
+ * contexts then share that GPU).  Every call runs one host thread per device for its duration and gives device k the
+ * contiguous shard [k n / G, (k + 1) n / G) of the batch; results land in the caller's buffers at the items' own
+ * positions, so the output is identical to the single-context call's.  Independent items need no exchange between
+ * devices.  The product forms (multi_miller_loop_native / native_pairing over all pairs,
+ * src/native/miller_loop.rs:121-162, src/native/pairing.rs:8-13) reduce each shard to one Fq12 on its device, gather
+ * the G partials (576 bytes each) on the host and multiply them - and run the one final exponentiation - on the
+ * first device.  Host pointers throughout. */
+typedef struct bls381_multi_ctx bls381_multi_ctx;
+int bls381_multi_ctx_create(bls381_multi_ctx** out, const int* device_ids, int n_devices);
+void bls381_multi_ctx_destroy(bls381_multi_ctx*);
+int bls381_multi_ctx_devices(const bls381_multi_ctx*);
+int bls381_multi_ctx_pairing_batch(bls381_multi_ctx*, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf_flags, size_t n,
+                                   uint64_t* out_fq12);
+int bls381_multi_ctx_miller_loop_batch(bls381_multi_ctx*, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf_flags,
+                                       size_t n, uint64_t* out_fq12);
+int bls381_multi_ctx_final_exp_batch(bls381_multi_ctx*, const uint64_t* in_fq12, size_t n, uint64_t* out_fq12,
+                                     uint8_t* is_zero_err);
+int bls381_multi_ctx_multi_miller_loop(bls381_multi_ctx*, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf_flags,
+                                       size_t n_pairs, uint64_t out_fq12[72]);
+int bls381_multi_ctx_multi_pairing(bls381_multi_ctx*, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf_flags,
+                                   size_t n_pairs, uint64_t out_fq12[72], int* is_one);
+int bls381_multi_ctx_pairing_witness_batch(bls381_multi_ctx*, const uint64_t* g1, const uint64_t* g2, size_t n_proofs,
+                                           uint32_t* trace);
+int bls381_multi_ctx_verify_batch(bls381_multi_ctx*, const uint8_t* pk48, const uint8_t* msg96, const uint8_t* sig96, size_t n,
+                                  int check_subgroup_mask, uint8_t* verdict, uint8_t* status);
+
 /* bls381_pairing_batch_dev for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same kernels and results as
  * bls381_pairing_batch_dev, but the workspace (slot arrays, carry and spill arrays) is a fixed 32 MiB array that

@@ -77,6 +77,16 @@ _sig("bls381_pairing_two_pairs_batch_dev", C.c_int, ctxp, C.c_void_p, C.c_void_p
 _sig("bls381_verify_batch", C.c_int, ctxp, u8p, u8p, u8p, C.c_size_t, C.c_int, u8p, u8p)
 _sig("bls381_fast_aggregate_verify", C.c_int, ctxp, u8p, C.c_size_t, u8p, u8p, C.c_int, C.POINTER(C.c_int), u8p)
 _sig("bls381_fast_aggregate_verify_batch", C.c_int, ctxp, u8p, C.c_size_t, C.c_size_t, u8p, u8p, C.c_int, u8p, u8p)
+_sig("bls381_multi_ctx_create", C.c_int, C.POINTER(ctxp), C.POINTER(C.c_int), C.c_int)
+_sig("bls381_multi_ctx_destroy", None, ctxp)
+_sig("bls381_multi_ctx_devices", C.c_int, ctxp)
+_sig("bls381_multi_ctx_pairing_batch", C.c_int, ctxp, u64p, u64p, u8p, C.c_size_t, u64p)
+_sig("bls381_multi_ctx_miller_loop_batch", C.c_int, ctxp, u64p, u64p, u8p, C.c_size_t, u64p)
+_sig("bls381_multi_ctx_final_exp_batch", C.c_int, ctxp, u64p, C.c_size_t, u64p, u8p)
+_sig("bls381_multi_ctx_multi_miller_loop", C.c_int, ctxp, u64p, u64p, u8p, C.c_size_t, u64p)
+_sig("bls381_multi_ctx_multi_pairing", C.c_int, ctxp, u64p, u64p, u8p, C.c_size_t, u64p, C.POINTER(C.c_int))
+_sig("bls381_multi_ctx_pairing_witness_batch", C.c_int, ctxp, u64p, u64p, C.c_size_t, u32p)
+_sig("bls381_multi_ctx_verify_batch", C.c_int, ctxp, u8p, u8p, u8p, C.c_size_t, C.c_int, u8p, u8p)
 _sig("bls381_debug_program", C.c_int, C.c_char_p, C.c_int, C.c_int, u32p, u32p, C.c_size_t, u32p)
 _sig("bls381_debug_constants", C.c_int, u32p, C.c_size_t)
 _sig("bls381_debug_profile", C.c_int, C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64))
@@ -98,6 +108,9 @@ EXPORTED = [
     "bls381_miller_loop_fixed_q_batch", "bls381_pairing_fixed_q_batch", "bls381_pairing_fixed_q_batch_dev", "bls381_debug_program", "bls381_debug_constants", "bls381_debug_profile", "bls381_debug_fp_mul", "bls381_debug_fp_inverse", "bls381_last_timing",
     "bls381_calibrate_mac_rate", "bls381_g1_decompress_batch", "bls381_g2_decompress_batch", "bls381_g1_compress_batch",
     "bls381_g2_compress_batch", "bls381_g1_aggregate_batch", "bls381_g2_aggregate_batch",
+    "bls381_multi_ctx_create", "bls381_multi_ctx_destroy", "bls381_multi_ctx_devices", "bls381_multi_ctx_pairing_batch",
+    "bls381_multi_ctx_miller_loop_batch", "bls381_multi_ctx_final_exp_batch", "bls381_multi_ctx_multi_miller_loop",
+    "bls381_multi_ctx_multi_pairing", "bls381_multi_ctx_pairing_witness_batch", "bls381_multi_ctx_verify_batch",
     "bls381_miller_loop_two_pairs_batch", "bls381_pairing_two_pairs_batch", "bls381_pairing_two_pairs_batch_dev", "bls381_verify_batch", "bls381_fast_aggregate_verify", "bls381_fast_aggregate_verify_batch",
 ]
 

@@ -10,6 +10,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bls381_constants.h"
@@ -1174,6 +1175,124 @@ extern "C" int bls381_finish_multi_pairing(bls381_ctx* c, const uint64_t* partia
         *is_one = std::memcmp(out, one, sizeof one) == 0;
     }
     return 0;
+}
+
+// ------------------------------------------------------------------ several GPUs behind one handle
+// One context per listed device, one host thread per device for the duration of a call, contiguous shards
+// [k n / G, (k + 1) n / G), results into disjoint slices of the caller's buffers: independent items need no
+// exchange between the devices.  The product form gathers one 576-byte partial product per device on the host
+// and finishes on the first device.  A device may be listed more than once (two contexts then share it).
+struct bls381_multi_ctx {
+    std::vector<bls381_ctx*> ctxs;
+};
+extern "C" int bls381_multi_ctx_create(bls381_multi_ctx** out, const int* device_ids, int n_devices) {
+    if (!out) return fail(BLS381_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!device_ids || n_devices <= 0 || n_devices > 64) return fail(BLS381_ERR_INVALID, "1 to 64 device ids are needed");
+    bls381_multi_ctx* m = new bls381_multi_ctx();
+    for (int k = 0; k < n_devices; k++) {
+        bls381_ctx* c = nullptr;
+        int rc = bls381_ctx_create(&c, device_ids[k]);
+        if (rc) {
+            const std::string why = g_err;
+            for (bls381_ctx* x : m->ctxs) bls381_ctx_destroy(x);
+            delete m;
+            return fail(rc, "device " + std::to_string(device_ids[k]) + ": " + why);
+        }
+        m->ctxs.push_back(c);
+    }
+    *out = m;
+    return 0;
+}
+extern "C" void bls381_multi_ctx_destroy(bls381_multi_ctx* m) {
+    if (!m) return;
+    for (bls381_ctx* c : m->ctxs) bls381_ctx_destroy(c);
+    delete m;
+}
+extern "C" int bls381_multi_ctx_devices(const bls381_multi_ctx* m) { return m ? (int)m->ctxs.size() : 0; }
+
+// runs fn(k, ctx, offset, count) for every device on its own thread; the first failure (lowest k) is reported
+template <class Fn>
+static int shard_run(bls381_multi_ctx* m, size_t n, Fn fn) {
+    if (!m) return fail(BLS381_ERR_INVALID, "multi-device context is NULL");
+    const size_t G = m->ctxs.size();
+    std::vector<int> rcs(G, 0);
+    std::vector<std::string> errs(G);
+    std::vector<std::thread> threads;
+    for (size_t k = 0; k < G; k++) {
+        const size_t lo = n * k / G, hi = n * (k + 1) / G;
+        threads.emplace_back([&, k, lo, hi]() {
+            rcs[k] = fn(k, m->ctxs[k], lo, hi - lo);
+            if (rcs[k]) errs[k] = g_err;  // (thread-local: carried back to the caller's thread below)
+        });
+    }
+    for (auto& t : threads) t.join();
+    for (size_t k = 0; k < G; k++)
+        if (rcs[k]) return fail(rcs[k], "device slot " + std::to_string(k) + ": " + errs[k]);
+    return 0;
+}
+#define SHARD_PTR(p, elems) ((p) ? (p) + off * (elems) : nullptr)
+extern "C" int bls381_multi_ctx_pairing_batch(bls381_multi_ctx* m, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags,
+                                              size_t n, uint64_t* out) {
+    return shard_run(m, n, [&](size_t, bls381_ctx* c, size_t off, size_t cnt) {
+        return bls381_pairing_batch(c, SHARD_PTR(g1, 12), SHARD_PTR(g2, 24), SHARD_PTR(flags, 1), cnt, SHARD_PTR(out, 72));
+    });
+}
+extern "C" int bls381_multi_ctx_miller_loop_batch(bls381_multi_ctx* m, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags,
+                                                  size_t n, uint64_t* out) {
+    return shard_run(m, n, [&](size_t, bls381_ctx* c, size_t off, size_t cnt) {
+        return bls381_miller_loop_batch(c, SHARD_PTR(g1, 12), SHARD_PTR(g2, 24), SHARD_PTR(flags, 1), cnt, SHARD_PTR(out, 72));
+    });
+}
+extern "C" int bls381_multi_ctx_final_exp_batch(bls381_multi_ctx* m, const uint64_t* in, size_t n, uint64_t* out, uint8_t* zero) {
+    return shard_run(m, n, [&](size_t, bls381_ctx* c, size_t off, size_t cnt) {
+        return bls381_final_exp_batch(c, SHARD_PTR(in, 72), cnt, SHARD_PTR(out, 72), SHARD_PTR(zero, 1));
+    });
+}
+extern "C" int bls381_multi_ctx_pairing_witness_batch(bls381_multi_ctx* m, const uint64_t* g1, const uint64_t* g2, size_t n,
+                                                      uint32_t* trace) {
+    const size_t row_words = bls381_pairing_witness_rows() * 12;
+    return shard_run(m, n, [&](size_t, bls381_ctx* c, size_t off, size_t cnt) {
+        return bls381_pairing_witness_batch(c, SHARD_PTR(g1, 12), SHARD_PTR(g2, 24), cnt, SHARD_PTR(trace, row_words));
+    });
+}
+extern "C" int bls381_multi_ctx_verify_batch(bls381_multi_ctx* m, const uint8_t* pk48, const uint8_t* msg96, const uint8_t* sig96,
+                                             size_t n, int check_subgroup, uint8_t* verdict, uint8_t* status) {
+    return shard_run(m, n, [&](size_t, bls381_ctx* c, size_t off, size_t cnt) {
+        return bls381_verify_batch(c, SHARD_PTR(pk48, 48), SHARD_PTR(msg96, 96), SHARD_PTR(sig96, 96), cnt, check_subgroup,
+                                   SHARD_PTR(verdict, 1), SHARD_PTR(status, 3));
+    });
+}
+// multi_miller_loop_native / native_pairing over all n pairs: every device reduces its shard to one Fq12 (an empty
+// shard gives one), the partials are multiplied on the first device (conjugation is multiplicative, so the
+// per-shard values, each already conjugated, multiply to the value of the whole).
+static int multi_ctx_product(bls381_multi_ctx* m, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags, size_t n,
+                             uint64_t out[72], int* is_one, bool fe) {
+    if (!m) return fail(BLS381_ERR_INVALID, "multi-device context is NULL");
+    if (!out) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    std::vector<uint64_t> partials(m->ctxs.size() * 72);
+    int rc = shard_run(m, n, [&](size_t k, bls381_ctx* c, size_t off, size_t cnt) {
+        return bls381_multi_miller_loop(c, SHARD_PTR(g1, 12), SHARD_PTR(g2, 24), SHARD_PTR(flags, 1), cnt, &partials[k * 72]);
+    });
+    if (rc) return rc;
+    bls381_ctx* c = m->ctxs[0];
+    if (fe) return bls381_finish_multi_pairing(c, partials.data(), m->ctxs.size(), out, is_one);
+    // product only: fold the partials with the Fq12 product
+    std::vector<uint64_t> acc(partials.begin(), partials.begin() + 72), next(72);
+    for (size_t k = 1; k < m->ctxs.size(); k++) {
+        if ((rc = bls381_fq12_mul_batch(c, acc.data(), &partials[k * 72], 1, next.data()))) return rc;
+        acc.swap(next);
+    }
+    std::memcpy(out, acc.data(), 576);
+    return 0;
+}
+extern "C" int bls381_multi_ctx_multi_miller_loop(bls381_multi_ctx* m, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags,
+                                                  size_t n, uint64_t out[72]) {
+    return multi_ctx_product(m, g1, g2, flags, n, out, nullptr, false);
+}
+extern "C" int bls381_multi_ctx_multi_pairing(bls381_multi_ctx* m, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags,
+                                              size_t n, uint64_t out[72], int* is_one) {
+    return multi_ctx_product(m, g1, g2, flags, n, out, is_one, true);
 }
 
 // ------------------------------------------------------------------ Fq12 inverse on witness limbs

@@ -477,6 +477,98 @@ class Context:
         return self._h
 
 
+class MultiContext:
+    """Several GPUs behind one handle (bls381_multi_ctx): contiguous shards, one host thread per device."""
+
+    def __init__(self, device_ids):
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        self._h = C.c_void_p()
+        check(lib.bls381_multi_ctx_create(C.byref(self._h), ids, len(device_ids)))
+
+    def close(self):
+        if self._h:
+            lib.bls381_multi_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def devices(self):
+        return lib.bls381_multi_ctx_devices(self._h)
+
+    def _pairs(self, fn, g1, g2, inf_flags):
+        g1, g2 = _arr64(g1, 12), _arr64(g2, 24)
+        n = g1.shape[0]
+        if g2.shape[0] != n:
+            raise ValueError("zip_eq: length mismatch")
+        fl = _flags(inf_flags, n)
+        out = np.empty((n, 72), dtype=np.uint64)
+        check(fn(self._h, _p64(g1), _p64(g2), _p8(fl), n, _p64(out)))
+        return out
+
+    def pairing_batch(self, g1, g2, inf_flags=None):
+        return self._pairs(lib.bls381_multi_ctx_pairing_batch, g1, g2, inf_flags)
+
+    def miller_loop_batch(self, g1, g2, inf_flags=None):
+        return self._pairs(lib.bls381_multi_ctx_miller_loop_batch, g1, g2, inf_flags)
+
+    def final_exponentiation_batch(self, fq12):
+        fq12 = _arr64(fq12, 72)
+        n = fq12.shape[0]
+        out = np.empty((n, 72), dtype=np.uint64)
+        z = np.zeros(n, dtype=np.uint8)
+        check(lib.bls381_multi_ctx_final_exp_batch(self._h, _p64(fq12), n, _p64(out), _p8(z)))
+        return out
+
+    def multi_miller_loop_native(self, g1, g2, inf_flags=None):
+        g1, g2 = _arr64(g1, 12), _arr64(g2, 24)
+        n = g1.shape[0]
+        fl = _flags(inf_flags, n)
+        out = np.empty(72, dtype=np.uint64)
+        check(lib.bls381_multi_ctx_multi_miller_loop(self._h, _p64(g1), _p64(g2), _p8(fl), n, _p64(out)))
+        return out
+
+    def native_pairing(self, g1, g2, inf_flags=None):
+        g1, g2 = _arr64(g1, 12), _arr64(g2, 24)
+        n = g1.shape[0]
+        fl = _flags(inf_flags, n)
+        out = np.empty(72, dtype=np.uint64)
+        one = C.c_int(0)
+        check(lib.bls381_multi_ctx_multi_pairing(self._h, _p64(g1), _p64(g2), _p8(fl), n, _p64(out), C.byref(one)))
+        return out, bool(one.value)
+
+    def pairing_witness_batch(self, g1, g2):
+        g1, g2 = _arr64(g1, 12), _arr64(g2, 24)
+        n = g1.shape[0]
+        if g2.shape[0] != n:
+            raise ValueError("g1 and g2 must have one row per proof")
+        trace = np.empty((n, lib.bls381_pairing_witness_rows(), 12), dtype=np.uint32)
+        check(lib.bls381_multi_ctx_pairing_witness_batch(self._h, _p64(g1), _p64(g2), n, _p32(trace)))
+        return trace
+
+    def verify_batch(self, pk, msg, sig, check_subgroup=7):
+        pk = np.ascontiguousarray(pk, dtype=np.uint8)
+        msg = np.ascontiguousarray(msg, dtype=np.uint8)
+        sig = np.ascontiguousarray(sig, dtype=np.uint8)
+        n = pk.shape[0]
+        if pk.shape != (n, 48) or msg.shape != (n, 96) or sig.shape != (n, 96):
+            raise ValueError("expected shapes (n, 48), (n, 96), (n, 96)")
+        verdict = np.zeros(n, dtype=np.uint8)
+        status = np.zeros((n, 3), dtype=np.uint8)
+        check(lib.bls381_multi_ctx_verify_batch(self._h, _p8(pk), _p8(msg), _p8(sig), n, int(check_subgroup), _p8(verdict), _p8(status)))
+        return verdict, status
+
+
 def witness_rows():
     return lib.bls381_pairing_witness_rows()
 

@@ -837,6 +837,58 @@ def test_concurrent_callers(ctx, CO):
         assert np.array_equal(results[t][probe], CO.pairing_batch(jobs[t][0][probe], jobs[t][1][probe])), t
 
 
+def test_multi_device_context(ctx, CO):
+    """bls381_multi_ctx over a device list: the one-GPU box lists device 0 twice and three times, so the shards run
+    on separate contexts and host threads as they would on separate GPUs.  Results must equal the one-context
+    calls bit for bit: a 65,536 + 777 batch of independent pairings with infinity flags on both sides of a shard
+    boundary, the 513-pair product (valid and forged), sizes smaller than the device count, and the witness
+    trace."""
+    import plonky2_bls12_381_pairing_amd as B
+    n = 65536 + 777
+    ps, qs = H.random_pairs(7, 2025)
+    g1 = np.tile(H.g1_array(ps), (n // 7 + 1, 1))[:n]
+    g2 = np.roll(np.tile(H.g2_array(qs), (n // 7 + 1, 1))[:n], 3, 0)
+    flags = np.zeros(n, np.uint8)
+    flags[[0, n // 2 - 1, n // 2, n - 1]] = [1, 2, 3, 1]
+    want = ctx.pairing_batch(g1, g2, flags)
+    with B.MultiContext([0, 0]) as m2, B.MultiContext([0, 0, 0]) as m3:
+        assert m2.devices == 2 and m3.devices == 3
+        assert np.array_equal(m2.pairing_batch(g1, g2, flags), want)
+        k = 1000
+        assert np.array_equal(m3.pairing_batch(g1[:k], g2[:k], flags[:k]), want[:k])
+        assert np.array_equal(m3.miller_loop_batch(g1[:k], g2[:k], flags[:k]), ctx.miller_loop_batch(g1[:k], g2[:k], flags[:k]))
+        assert np.array_equal(m2.final_exponentiation_batch(want[:50]), ctx.final_exponentiation_batch(want[:50]))
+        # fewer items than devices, and none
+        assert np.array_equal(m3.pairing_batch(g1[:2], g2[:2]), want[:2] if not flags[:2].any() else ctx.pairing_batch(g1[:2], g2[:2]))
+        assert m3.pairing_batch(g1[:0], g2[:0]).shape == (0, 72)
+        # the aggregate-signature product: 512 (pk_i, H_i) pairs and (-G1, sigma)
+        import random
+        rng = random.Random(77)
+        sks = [rng.randrange(1, R.R_ORDER) for _ in range(8)]
+        hs = [rng.randrange(1, R.R_ORDER) for _ in range(8)]
+        pk = [R.g1_mul(R.G1_GEN, s) for s in sks]
+        hm = [R.g2_mul(R.G2_GEN, h) for h in hs]
+        idx = [(i % 8, (i // 8) % 8) for i in range(512)]
+        total = sum(sks[a] * hs[b] for a, b in idx) % R.R_ORDER
+        sigma = R.g2_mul(R.G2_GEN, total)
+        a1 = H.g1_array([pk[a] for a, _ in idx] + [R.g1_neg(R.G1_GEN)])
+        a2 = H.g2_array([hm[b] for _, b in idx] + [sigma])
+        for mc in (m2, m3):
+            out, one = mc.native_pairing(a1, a2)
+            assert one and np.array_equal(out, ctx.native_pairing(a1, a2)[0])
+            assert np.array_equal(mc.multi_miller_loop_native(a1, a2), ctx.multi_miller_loop_native(a1, a2))
+        forged = a2.copy()
+        forged[-1] = H.g2_array([R.g2_mul(R.G2_GEN, total + 1)])[0]
+        out, one = m3.native_pairing(a1, forged)
+        assert not one and np.array_equal(out, ctx.native_pairing(a1, forged)[0])
+        out, one = m3.native_pairing(a1[:0], a2[:0])             # empty product on every shard
+        assert one
+        # witness traces, three proofs over two devices
+        assert np.array_equal(m2.pairing_witness_batch(g1[:3], g2[:3]), ctx.pairing_witness_batch(g1[:3], g2[:3]))
+    with pytest.raises(B.Bls381Error):
+        B.MultiContext([0, 99])
+
+
 def test_argument_errors_on_a_live_context(ctx):
     """NULL buffers, sizes past the documented limits and bad selectors: BLS381_ERR_INVALID, nothing launched,
     and the context keeps working afterwards."""
