@@ -146,6 +146,21 @@ int bls381_pairing_witness_batch(bls381_ctx*, const uint64_t* g1, const uint64_t
 int bls381_pairing_witness_batch_dev(bls381_ctx*, const uint64_t* g1, const uint64_t* g2, size_t n_proofs,
                                      uint32_t* trace);
 
+/* The trace together with the auxiliary witness values of the non-native gadgets behind FqTarget's add / sub / mul /
+ * neg / inv (src/fields/fq_target.rs:144-192; the gadgets and their generators live in plonky2_ecdsa at the
+ * InternetMaximalism fork's rev 541e127, Cargo.toml:8-10, which is not part of the reference tree: the VALUES below
+ * are determined by each row's operands, their limb LAYOUT in the fork is an assumption - parity unpinned).
+ * Any of the three outputs may be NULL.
+ *   mul_quot  n_proofs x bls381_pairing_witness_mul_rows() x 24 u32: per mul row, in row order, the quotient
+ *             (a * b - r) / p of the product by the modulus (what NonNativeMultiplicationGenerator's div_rem yields
+ *             next to the remainder r that is the row's value); below p, so limbs 12..23 are zero
+ *   carry     n_proofs x rows bytes: add rows 1 iff a + b >= p (the modulus was subtracted), sub rows 1 iff a < b (the
+ *             modulus was added), neg rows 1 iff a != 0 (neg is 0 - a), other rows 0
+ *   inv_quot  n_proofs x 24 u32: for the one inv row (inv_nonnative(2), src/curves/g2.rs:149-151) (a * a^-1 - 1) / p */
+size_t bls381_pairing_witness_mul_rows(void);
+int bls381_pairing_witness_aux_batch(bls381_ctx*, const uint64_t* g1, const uint64_t* g2, size_t n_proofs, uint32_t* trace,
+                                     uint32_t* mul_quot, uint8_t* carry, uint32_t* inv_quot);
+
 /* Device-resident variants: all pointers are device memory on the context's GPU; they run on the
  * context's stream and return after the work has completed. */
 int bls381_pairing_batch_dev(bls381_ctx*, const uint64_t* g1_dev, const uint64_t* g2_dev, const uint8_t* inf_flags_dev,

@@ -18,18 +18,44 @@ P = R.P
 class Trace:
     def __init__(self):
         self.rows = []          # list of (kind, value)
+        self.operands = []      # per row: (a, b) as the gadget received them (b None for neg / inv, both None for 'gen')
         self.counts = {'add': 0, 'sub': 0, 'mul': 0, 'neg': 0, 'inv': 0, 'gen': 0}
-    def emit(self, kind, v):
+    def emit(self, kind, v, a=None, b=None):
         self.rows.append((kind, v))
+        self.operands.append((a, b))
         self.counts[kind] += 1
         return v
+    def aux(self):
+        """The auxiliary values the non-native gadgets' generators compute beside each row's value (the gadgets are
+        plonky2_ecdsa's, absent from the reference tree: values by definition, layout unpinned): per mul row the
+        quotient (a b - r) / p, per row a carry byte (add: a + b >= p, sub: a < b, neg: a != 0), and the inv row's
+        quotient (a a^-1 - 1) / p."""
+        mul_quot, carry, inv_quot = [], [], None
+        for (kind, r), (a, b) in zip(self.rows, self.operands):
+            if kind == 'mul':
+                assert (a * b - r) % P == 0
+                mul_quot.append((a * b - r) // P)
+                carry.append(0)
+            elif kind == 'add':
+                carry.append(1 if a + b >= P else 0)
+            elif kind == 'sub':
+                carry.append(1 if a < b else 0)
+            elif kind == 'neg':
+                carry.append(1 if a != 0 else 0)
+            elif kind == 'inv':
+                assert (a * r - 1) % P == 0
+                inv_quot = (a * r - 1) // P
+                carry.append(0)
+            else:
+                carry.append(0)
+        return mul_quot, carry, inv_quot
 
 # ---- FqTarget ops (fq_target.rs:144-187): values are ints
-def fq_add(t, a, b): return t.emit('add', (a + b) % P)
-def fq_sub(t, a, b): return t.emit('sub', (a - b) % P)
-def fq_mul(t, a, b): return t.emit('mul', a * b % P)
-def fq_neg(t, a): return t.emit('neg', (-a) % P)
-def fq_inv(t, a): return t.emit('inv', R.fq_inv(a))
+def fq_add(t, a, b): return t.emit('add', (a + b) % P, a, b)
+def fq_sub(t, a, b): return t.emit('sub', (a - b) % P, a, b)
+def fq_mul(t, a, b): return t.emit('mul', a * b % P, a, b)
+def fq_neg(t, a): return t.emit('neg', (-a) % P, a)
+def fq_inv(t, a): return t.emit('inv', R.fq_inv(a), a)
 
 # ---- Fq2Target (fq2_target.rs): values are [c0, c1]
 def fq2_add(t, a, b): return [fq_add(t, a[0], b[0]), fq_add(t, a[1], b[1])]          # :94-104

@@ -23,6 +23,8 @@ u64p = C.POINTER(C.c_uint64)
 ctxp = C.c_void_p
 
 def _sig(name, restype, *argtypes):
+    if os.environ.get("BLS381_LIB_PATH") and not hasattr(lib, name):
+        return None  # an older build loaded for an A/B comparison may lack the newer entry points
     f = getattr(lib, name)
     f.restype = restype
     f.argtypes = list(argtypes)
@@ -51,6 +53,8 @@ _sig("bls381_fq12_inverse_limbs_batch", C.c_int, ctxp, u32p, C.c_size_t, u32p, u
 _sig("bls381_pairing_witness_rows", C.c_size_t)
 _sig("bls381_pairing_witness_kinds", C.c_int, u8p, C.c_size_t)
 _sig("bls381_pairing_witness_batch", C.c_int, ctxp, u64p, u64p, C.c_size_t, u32p)
+_sig("bls381_pairing_witness_mul_rows", C.c_size_t)
+_sig("bls381_pairing_witness_aux_batch", C.c_int, ctxp, u64p, u64p, C.c_size_t, u32p, u32p, u8p, u32p)
 _sig("bls381_pairing_witness_batch_dev", C.c_int, ctxp, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 _sig("bls381_pairing_batch_dev", C.c_int, ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 _sig("bls381_pairing_batch_dev_noalloc", C.c_int, ctxp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -102,7 +106,7 @@ EXPORTED = [
     "bls381_multi_pairing", "bls381_finish_multi_pairing", "bls381_g2_prepare_batch", "bls381_ell_batch",
     "bls381_easy_part_batch", "bls381_hard_part_batch", "bls381_frobenius_batch", "bls381_conjugate_batch", "bls381_pow_batch", "bls381_pow_x_batch", "bls381_fq12_mul_batch",
     "bls381_fq12_inverse_limbs_batch", "bls381_pairing_witness_rows", "bls381_pairing_witness_kinds",
-    "bls381_pairing_witness_batch", "bls381_pairing_witness_batch_dev", "bls381_pairing_batch_dev", "bls381_pairing_batch_dev_noalloc", "bls381_miller_loop_batch_dev",
+    "bls381_pairing_witness_batch", "bls381_pairing_witness_mul_rows", "bls381_pairing_witness_aux_batch", "bls381_pairing_witness_batch_dev", "bls381_pairing_batch_dev", "bls381_pairing_batch_dev_noalloc", "bls381_miller_loop_batch_dev",
     "bls381_final_exp_batch_dev", "bls381_g2_prepared_create", "bls381_g2_prepared_destroy",
     "bls381_fq_sqrt_limbs_batch", "bls381_fq2_sqrt_limbs_batch", "bls381_fq2_inverse_limbs_batch", "bls381_fq6_inverse_limbs_batch",
     "bls381_miller_loop_fixed_q_batch", "bls381_pairing_fixed_q_batch", "bls381_pairing_fixed_q_batch_dev", "bls381_debug_program", "bls381_debug_constants", "bls381_debug_profile", "bls381_debug_fp_mul", "bls381_debug_fp_inverse", "bls381_last_timing",

@@ -1375,6 +1375,22 @@ extern "C" int bls381_pairing_witness_batch(bls381_ctx* c, const uint64_t* g1, c
     return 0;
 }
 
+extern "C" size_t bls381_pairing_witness_mul_rows(void) { return witness_program().counts[WK_MUL]; }
+extern "C" int bls381_pairing_witness_aux_batch(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t n, uint32_t* trace,
+                                                uint32_t* mul_quot, uint8_t* carry, uint32_t* inv_quot) {
+    CTX_GUARD(c);
+    if (n == 0) return 0;
+    if (!g1 || !g2 || !trace) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    std::string err;
+    auto inv = [](void* cx, const uint32_t* x_dev, size_t m, uint32_t* inv_dev) -> int {
+        return inverse_limbs_dev_locked((bls381_ctx*)cx, x_dev, m, inv_dev, nullptr);
+    };
+    const WitnessAux aux{mul_quot, carry, inv_quot};
+    int rc = c->wit.run(c->stream, c, inv, g1, g2, n, trace, err, /*on_device=*/false, &aux);
+    if (rc) return fail(rc, err.empty() ? g_err : err);
+    return 0;
+}
+
 extern "C" int bls381_pairing_witness_batch_dev(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, size_t n,
                                                 uint32_t* trace) {
     CTX_GUARD(c);

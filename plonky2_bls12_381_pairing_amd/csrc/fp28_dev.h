@@ -192,27 +192,20 @@ __device__ __forceinline__ void coef_mad28(u64* acc, const u32* x, u32 k) {
         : "vcc");
 }
 
-// Digits in [-8 * (2^28 - 1), 7 * 2^28], |value| below 2500 p  ->  normalised, value in (-0.2 p, 1.2 p):
-// sweeps (after which the subtraction below cannot leave 32 bits), then subtracts q * p, q = an estimate of
-// value / p from the top digit, in a second sweep.
+// Digits of magnitude up to 7 * 2^28, |value| below 2500 p  ->  normalised, value in (-0.2 p, 1.2 p):
+// subtracts q * p, q = an estimate of value / p from the top digit (the carries still owed to it
+// move it by at most 8, 1e-4 of p's top digit), then sweeps.
 __device__ __forceinline__ void reduce28(u32* d) {
     const u32 P[D28] = BLS381_P28_DIGITS;
-    normalise28(d);
     const int q = __mulhi((int)d[D28 - 1], 40323);  // floor(top * floor(2^32 / (top digit of p + 1)) / 2^32)
     int64_t c = 0;
-    int carry = 0;
 #pragma unroll
     for (int i = 0; i < D28; i++) {
         c += (int64_t)q * (int)P[i];
-        if (i < D28 - 1) {
-            const int t = (int)d[i] - (int)((u32)c & BLS381_MASK28) + carry;
-            d[i] = (u32)t & BLS381_MASK28;
-            carry = t >> 28;
-        } else {
-            d[i] = d[i] - (u32)c + (u32)carry;  // the top digit takes what is left, sign included
-        }
+        d[i] -= (i < D28 - 1) ? ((u32)c & BLS381_MASK28) : (u32)c;  // the top digit takes what is left, sign included
         c >>= 28;
     }
+    normalise28(d);
 }
 
 // Normalised value in (-p, 2p) -> [0, p)

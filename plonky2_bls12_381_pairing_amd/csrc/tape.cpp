@@ -51,9 +51,9 @@ static std::vector<Term> merge_terms(const std::vector<Term>& in) {
     for (auto& o : out) if (o.coef != 0) nz.push_back(o);
     return nz;
 }
-// Digits are signed 32-bit numbers: a sum of normalised values (digits in [0, 2^28)) stays inside them while its
-// positive coefficients add up to at most 7 and its negative ones to at most 8, or, computed around a shifted
-// zero (see the scheduler's bound analysis), while both together add up to at most 15.
+// Digits are signed 32-bit numbers with some room kept for the reduction's arithmetic: a sum of normalised values
+// (digits in [0, 2^28)) is fine while its positive and its negative coefficients each add up to at most 7, or,
+// computed around a shifted zero (see the scheduler's bound analysis), while both together add up to at most 14.
 static bool coefficients_fit(const std::vector<Term>& terms) {
     int pos = 0, neg = 0;
     for (auto& t : terms) {
@@ -61,7 +61,7 @@ static bool coefficients_fit(const std::vector<Term>& terms) {
         (t.coef > 0 ? pos : neg) += std::abs(t.coef);
     }
     static const bool use_bias = env_int("BLS381_LIN_BIAS", 1) != 0;
-    return use_bias ? pos + neg <= 15 : (pos <= 7 && neg <= 8);
+    return use_bias ? pos + neg <= 14 : (pos <= 7 && neg <= 7);
 }
 int Dag::lin(std::vector<Term> terms) {
     assert(!terms.empty());
@@ -284,7 +284,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
     // (1 + sum / 2520) p.  The hard limits are the 28-bit top digit of an operand, vb <= 2047, and the
     // same for results.)
     const long MUL_VB_LIMIT = 2520L * 2046, MUL_DB_LIMIT = 8;
-    const int SUM_VB_LIMIT = 2047, SUM_HI_LIMIT = 7, SUM_LO_LIMIT = -8;  // 7 * 2^28 and -8 * (2^28 - 1) are 32-bit digits
+    const int SUM_VB_LIMIT = 2047, SUM_HI_LIMIT = 7, SUM_LO_LIMIT = -7;  // digits of magnitude up to 7 * 2^28: what the reduction takes
     std::vector<int> vb(n, 1), dlo(n, 0), dhi(n, 1), dmag(n, 1);
     std::vector<char> lin_norm(n, 0), lin_reduce(n, 0);
     std::vector<int> lin_bias(n, 0);  // sums whose digits only fit 32 bits around a shifted zero, see below
@@ -368,8 +368,10 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                     int bias = 0;
                     bool fits = b.hi <= SUM_HI_LIMIT && b.lo >= SUM_LO_LIMIT;
                     if (!fits && use_bias && b.hi - b.lo <= SUM_HI_LIMIT - SUM_LO_LIMIT) {
-                        bias = b.hi > SUM_HI_LIMIT ? SUM_HI_LIMIT - b.hi : SUM_LO_LIMIT - b.lo;
-                        fits = bias >= -8 && bias <= 7;
+                        bias = -((b.hi + b.lo) / 2);  // centred
+                        if (b.hi + bias > SUM_HI_LIMIT) bias = SUM_HI_LIMIT - b.hi;
+                        if (b.lo + bias < SUM_LO_LIMIT) bias = SUM_LO_LIMIT - b.lo;
+                        fits = bias >= -8 && bias <= 7 && b.hi + bias <= SUM_HI_LIMIT && b.lo + bias >= SUM_LO_LIMIT;
                         if (!fits) bias = 0;
                     }
                     if (b.v > SUM_VB_LIMIT) treated(widest(ops, vb, lin_reduce), lin_reduce, n_reduce);

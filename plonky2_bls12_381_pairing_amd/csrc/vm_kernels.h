@@ -34,7 +34,8 @@ struct VmArgs {
 };
 
 enum { VM_THREADS = 256 };
-typedef const unsigned long long __attribute__((address_space(1))) * global_u64_ptr;
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef const u32x2_t __attribute__((address_space(1))) * global_u32x2_ptr;
 
 __device__ __forceinline__ void unpack3(const uint4& a, const uint4& b, const uint4& c, u32* x) {
     x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
@@ -171,10 +172,9 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                     // the reuse then has to wait for the load
                     // (a pointer known to be global memory: laundered as a generic pointer the load would be a flat
                     // load, which counts as LDS traffic too and makes every later wait a wait for everything)
-                    global_u64_ptr pt = (global_u64_ptr)(p + 3);
+                    global_u32x2_ptr pt = (global_u32x2_ptr)(p + 3);
                     asm volatile("" : "+v"(pt));  // keeps the compiler from widening the load again
-                    const unsigned long long t3 = *pt;
-                    const uint2 v3 = make_uint2((u32)t3, (u32)(t3 >> 32));
+                    const u32x2_t v3 = *pt;
                     unpack3(v0, v1, v2, pf);
                     pf[12] = v3.x; pf[13] = v3.y;
                 } else {
@@ -189,16 +189,19 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             }
         }
 
+        // (the spilled value's registers stay reserved until the step ends, see there: gfx9 has one counter for
+        // loads and stores, and reusing a register a store still reads from means waiting for that store, which,
+        // the counter being in order, means waiting for the fills' loads issued before it)
+        u32 sv[D28];
         if (carries && (hx & (1u << 24))) {
             if (lane_on && (dw & (1u << 27))) {
-                u32 v[D28];
-                lds_load((dw >> 20) & 0x7fu, v);
+                lds_load((dw >> 20) & 0x7fu, sv);
                 const u32 t = dx >> 25;
                 uint4* p = A.gtmp + ((size_t)t * 3) * A.npad + e;
-                p[0] = make_uint4(v[0], v[1], v[2], v[3]);
-                p[A.npad] = make_uint4(v[4], v[5], v[6], v[7]);
-                p[2 * (size_t)A.npad] = make_uint4(v[8], v[9], v[10], v[11]);
-                A.gtmp_tail[(size_t)t * A.npad + e] = make_uint2(v[12], v[13]);
+                p[0] = make_uint4(sv[0], sv[1], sv[2], sv[3]);
+                p[A.npad] = make_uint4(sv[4], sv[5], sv[6], sv[7]);
+                p[2 * (size_t)A.npad] = make_uint4(sv[8], sv[9], sv[10], sv[11]);
+                A.gtmp_tail[(size_t)t * A.npad + e] = make_uint2(sv[12], sv[13]);
             }
         }
         // Multiplier and sum steps are branch-free: idle lanes read the ZERO slot and store to TRASH.
@@ -207,18 +210,19 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             // (64-bit accumulators whose low halves are the digits; the high halves mean nothing).  The loads
             // of up to four terms are issued together so their latencies overlap.  Sums shorter than the
             // step's longest are padded with 0 * ZERO.
+            // the shifted zero a sum starts from: B * 2^28 on digit 0, B * 2^28 - B on digits 1..12, -B on top
+            auto COEF = [](u32 w) -> u32 { return (u32)((int)(w << 17) >> 24); };  // bits 7..14, sign-extended
             u64 acc[D28];
-            auto TERM = [&](int i) -> u32 { return ((i < 2 ? dy : (i < 4 ? dz : (i < 6 ? d3 : d4))) >> ((i & 1) * 16)) & 0x7fffu; };
-            // the shifted zero the sum starts from: B * 2^28 on digit 0, B * 2^28 - B on digits 1..12, -B on top
             const int B = (int)(dx << 16) >> 28;  // bits 12..15, signed
             const u64 z0 = (u32)(B << 28), zm = (u32)((B << 28) - B), zt = (u32)(-B);
+            auto TERM = [&](int i) -> u32 { return ((i < 2 ? dy : (i < 4 ? dz : (i < 6 ? d3 : d4))) >> ((i & 1) * 16)) & 0x7fffu; };
             auto terms = [&](auto first_tag, auto count_tag) {
                 constexpr int T0 = decltype(first_tag)::value, N = decltype(count_tag)::value;
                 u32 x[N][D28], k[N];
 #pragma unroll
                 for (int t = 0; t < N; t++) {
                     const u32 w = TERM(T0 + t);
-                    k[t] = (u32)((int)(w << 17) >> 24);  // bits 7..14, sign-extended
+                    k[t] = COEF(w);
                     lds_load(w & 0x7fu, x[t]);
                 }
 #pragma unroll
@@ -324,10 +328,9 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                 } else if (kind == CK_CONST) {
                     const uint4* p = A.consts + (size_t)src * 4;
                     uint4 v0 = p[0], v1 = p[1], v2 = p[2];
-                    global_u64_ptr pt = (global_u64_ptr)(p + 3);
+                    global_u32x2_ptr pt = (global_u32x2_ptr)(p + 3);
                     asm volatile("" : "+v"(pt));
-                    const unsigned long long t3 = *pt;
-                    const uint2 v3 = make_uint2((u32)t3, (u32)(t3 >> 32));
+                    const u32x2_t v3 = *pt;
                     unpack3(v0, v1, v2, v);
                     v[12] = v3.x; v[13] = v3.y;
                 } else {
@@ -359,6 +362,9 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                 }
             }
         }
+        if (carries && (hx & (1u << 24)))
+            asm volatile("" : : "v"(sv[0]), "v"(sv[1]), "v"(sv[2]), "v"(sv[3]), "v"(sv[4]), "v"(sv[5]), "v"(sv[6]), "v"(sv[7]),
+                                "v"(sv[8]), "v"(sv[9]), "v"(sv[10]), "v"(sv[11]), "v"(sv[12]), "v"(sv[13]));
         if (carries && (hx & (1u << 23))) {
             // every path consumes the loaded registers here (see the copy step)
             asm volatile("" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]), "+v"(pf[6]),

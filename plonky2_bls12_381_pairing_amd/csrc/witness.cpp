@@ -312,6 +312,11 @@ WitnessProgram build_program() {
     P.n_rows = w.kinds.size();
     P.kinds = w.kinds;
     for (uint8_t kd : w.kinds) P.counts[kd]++;
+    P.mul_index.assign(P.n_rows, 0xffffffffu);
+    {
+        uint32_t k = 0;
+        for (size_t r = 0; r < P.n_rows; r++) if (P.kinds[r] == WK_MUL) P.mul_index[r] = k++;
+    }
     // level scheduling per phase
     std::vector<uint32_t> level(P.n_rows, 0);
     auto lvl = [&](uint32_t ref) -> uint32_t { return (ref >> 30) == 0 ? level[ref & WREF_MASK] + 1 : 0; };
@@ -460,6 +465,79 @@ __global__ void witness_scatter_kernel(u32* trace, size_t rows, size_t gen_start
     for (int l = 0; l < 12; l++) dst[l] = inv[(size_t)i * 12 + l];
 }
 
+// Auxiliary values of the non-native gadgets, one thread per (proof, operation), from the finished trace:
+//   mul rows: q = (a * b - r) / p (exact), 24 limbs   add rows: 1 when a + b >= p (p was subtracted)
+//   sub rows: 1 when a < b (p was added)   neg rows: 1 when a != 0 (computed as 0 - a)   inv row: (a * r - 1) / p
+// a, b = the row's operands, r = the row's value.
+__global__ void witness_aux_kernel(const WitnessOp* ops, int nops, const u32* mul_index, const u32* trace, size_t rows,
+                                   const u32* consts, const u32* inputs, int nproofs, size_t n_mul, u32* mul_quot, uint8_t* carry,
+                                   u32* inv_quot) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)nproofs * nops) return;
+    const int proof = (int)(t / nops);
+    const WitnessOp op = ops[t % nops];
+    const u32 kind = op.dst >> 28, row = op.dst & 0x0fffffffu;
+    const u32* T = trace + (size_t)proof * rows * 12;
+    const u32* in = inputs + (size_t)proof * 6 * 12;
+    const u32 P[12] = BLS381_P_LIMBS;
+    u32 a[12], b[12], r[12];
+    w_load(T, op.a, T, consts, in, a);
+    w_load(T, WREF_ROW | row, T, consts, in, r);
+    if (kind == WK_MUL || kind == WK_INV) {
+        if (kind == WK_MUL) w_load(T, op.b, T, consts, in, b);
+        else for (int k = 0; k < 12; k++) b[k] = r[k];  // a * a^-1
+        u32 w[24];
+        for (int k = 0; k < 24; k++) w[k] = 0;
+        for (int i = 0; i < 12; i++) {
+            u64 c = 0;
+            for (int j = 0; j < 12; j++) { c += (u64)a[i] * b[j] + w[i + j]; w[i + j] = (u32)c; c >>= 32; }
+            w[i + 12] = (u32)c;
+        }
+        // minus the remainder (r for a product, 1 for the inverse): the difference is an exact multiple of p
+        u32 borrow = 0;
+        for (int k = 0; k < 24; k++) {
+            const u32 sub = kind == WK_MUL ? (k < 12 ? r[k] : 0u) : (k == 0 ? 1u : 0u);
+            w[k] = subb(w[k], sub, borrow);
+        }
+        // exact division by the odd p, limb by limb from the bottom: q_i = w_i / p mod 2^32, then w -= q_i p 2^(32 i)
+        u32 q[24];
+        for (int k = 0; k < 24; k++) q[k] = 0;
+        for (int i = 0; i < 12; i++) {
+            const u32 qi = w[i] * 0x00030003u;  // p^-1 mod 2^32
+            q[i] = qi;
+            u64 c = 0;
+            u32 bw = 0;
+            for (int j = 0; j < 12; j++) {
+                c += (u64)qi * P[j];
+                w[i + j] = subb(w[i + j], (u32)c, bw);
+                c >>= 32;
+            }
+            for (int k = i + 12; k < 24; k++) { w[k] = subb(w[k], (u32)c, bw); c = 0; }
+        }
+        u32* dst = kind == WK_MUL ? mul_quot + ((size_t)proof * n_mul + mul_index[row]) * 24 : inv_quot + (size_t)proof * 24;
+        if (dst) for (int k = 0; k < 24; k++) dst[k] = q[k];
+        if (carry) carry[(size_t)proof * rows + row] = 0;
+        return;
+    }
+    uint8_t flag = 0;
+    if (kind == WK_ADD) {
+        w_load(T, op.b, T, consts, in, b);
+        u32 c = 0, differs = 0;
+        for (int k = 0; k < 12; k++) differs |= addc(a[k], b[k], c) ^ r[k];
+        flag = (c || differs) ? 1 : 0;
+    } else if (kind == WK_SUB) {
+        w_load(T, op.b, T, consts, in, b);
+        u32 bw = 0;
+        for (int k = 0; k < 12; k++) (void)subb(a[k], b[k], bw);
+        flag = (uint8_t)bw;
+    } else if (kind == WK_NEG) {
+        u32 nz = 0;
+        for (int k = 0; k < 12; k++) nz |= a[k];
+        flag = nz ? 1 : 0;
+    }
+    if (carry) carry[(size_t)proof * rows + row] = flag;
+}
+
 static void fill_wconsts(std::vector<uint32_t>& c) {
     c.assign((size_t)WC_COUNT * 12, 0);
     c[(size_t)WC_ONE * 12] = 1;
@@ -496,7 +574,7 @@ static hipError_t ensure(void*& p, size_t& have, size_t need) {
 }
 
 int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint64_t* g1, const uint64_t* g2, size_t n,
-                       uint32_t* trace, std::string& err, bool on_device) {
+                       uint32_t* trace, std::string& err, bool on_device, const WitnessAux* aux) {
     const WitnessProgram& P = witness_program();
     if (!uploaded_) {
         release();  // an earlier upload that failed half-way leaves nothing behind
@@ -512,6 +590,8 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         WCHK(hipMemcpy(d_consts_, wc.data(), wc.size() * 4, hipMemcpyHostToDevice));
         WCHK(hipMalloc((void**)&d_inv_refs_, 48));
         WCHK(hipMemcpy(d_inv_refs_, P.inv_input_refs, 48, hipMemcpyHostToDevice));
+        WCHK(hipMalloc((void**)&d_mul_index_, P.n_rows * 4));
+        WCHK(hipMemcpy(d_mul_index_, P.mul_index.data(), P.n_rows * 4, hipMemcpyHostToDevice));
         uploaded_ = true;
     }
     // Sixteen lanes per proof, four proofs per one-wave workgroup: dependency levels are about 35 rows wide
@@ -565,6 +645,37 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         hipLaunchKernelGGL(witness_kernel, dim3((m + per_block - 1) / per_block), dim3(block), 0, stream, d_ops_[1], d_levels_[1],
                            (int)P.level_start[1].size() - 1, d_trace_m, P.n_rows, d_consts_, (const u32*)d_inputs_, lpp, m);
         WCHK(hipGetLastError());
+        if (aux && (aux->mul_quot || aux->carry || aux->inv_quot)) {
+            const size_t n_mul = P.counts[WK_MUL];
+            // staged on the device per pass (host pointers) or written in place (device pointers)
+            u32* d_mq = nullptr; uint8_t* d_cy = nullptr; u32* d_iq = nullptr;
+            if (on_device) {
+                d_mq = aux->mul_quot ? aux->mul_quot + off * n_mul * 24 : nullptr;
+                d_cy = aux->carry ? aux->carry + off * P.n_rows : nullptr;
+                d_iq = aux->inv_quot ? aux->inv_quot + off * 24 : nullptr;
+            } else {
+                const size_t b_mq = aux->mul_quot ? (size_t)m * n_mul * 96 : 0, b_cy = aux->carry ? (size_t)m * P.n_rows : 0,
+                             b_iq = aux->inv_quot ? (size_t)m * 96 : 0;
+                WCHK(ensure(d_aux_, aux_bytes_, b_mq + b_cy + b_iq + 256));
+                char* base = (char*)d_aux_;
+                if (b_mq) d_mq = (u32*)base;
+                if (b_iq) d_iq = (u32*)(base + b_mq);
+                if (b_cy) d_cy = (uint8_t*)(base + b_mq + b_iq);
+            }
+            if (d_cy) WCHK(hipMemsetAsync(d_cy, 0, (size_t)m * P.n_rows, stream));  // generator rows carry nothing
+            for (int ph = 0; ph < 2; ph++) {
+                const long threads = (long)m * (long)P.ops[ph].size();
+                hipLaunchKernelGGL(witness_aux_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d_ops_[ph],
+                                   (int)P.ops[ph].size(), (const u32*)d_mul_index_, (const u32*)d_trace_m, P.n_rows, d_consts_,
+                                   (const u32*)d_inputs_, m, n_mul, d_mq, d_cy, d_iq);
+                WCHK(hipGetLastError());
+            }
+            if (!on_device) {
+                if (d_mq) WCHK(hipMemcpyAsync(aux->mul_quot + off * n_mul * 24, d_mq, (size_t)m * n_mul * 96, hipMemcpyDeviceToHost, stream));
+                if (d_cy) WCHK(hipMemcpyAsync(aux->carry + off * P.n_rows, d_cy, (size_t)m * P.n_rows, hipMemcpyDeviceToHost, stream));
+                if (d_iq) WCHK(hipMemcpyAsync(aux->inv_quot + off * 24, d_iq, (size_t)m * 96, hipMemcpyDeviceToHost, stream));
+            }
+        }
         if (!on_device) WCHK(hipMemcpyAsync(trace + off * P.n_rows * 12, d_trace_, tbytes, hipMemcpyDeviceToHost, stream));
         WCHK(hipStreamSynchronize(stream));
     }
@@ -573,9 +684,9 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
 
 void WitnessDevice::release() {
     for (int ph = 0; ph < 2; ph++) { if (d_ops_[ph]) (void)hipFree(d_ops_[ph]); if (d_levels_[ph]) (void)hipFree(d_levels_[ph]); d_ops_[ph] = nullptr; d_levels_[ph] = nullptr; }
-    for (void* p : {(void*)d_consts_, (void*)d_inv_refs_, d_trace_, d_inputs_, d_x_, d_g_}) if (p) (void)hipFree(p);
-    d_consts_ = nullptr; d_inv_refs_ = nullptr; d_trace_ = d_inputs_ = d_x_ = d_g_ = nullptr;
-    trace_bytes_ = inputs_bytes_ = x_bytes_ = g_bytes_ = 0;
+    for (void* p : {(void*)d_consts_, (void*)d_inv_refs_, (void*)d_mul_index_, d_trace_, d_inputs_, d_x_, d_g_, d_aux_}) if (p) (void)hipFree(p);
+    d_consts_ = nullptr; d_inv_refs_ = nullptr; d_mul_index_ = nullptr; d_trace_ = d_inputs_ = d_x_ = d_g_ = d_aux_ = nullptr;
+    trace_bytes_ = inputs_bytes_ = x_bytes_ = g_bytes_ = aux_bytes_ = 0;
     uploaded_ = false;
 }
 

@@ -46,6 +46,13 @@ struct WitnessProgram {
     std::vector<WitnessOp> ops[2];        // phase 0: rows before the generator output, phase 1: rows after
     std::vector<uint32_t> level_start[2]; // per phase, nlevels + 1 offsets into ops[phase]
     size_t counts[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<uint32_t> mul_index;      // per row: its ordinal among the mul rows (0xffffffff for other kinds)
+};
+// optional outputs beside the trace (any may be null): see bls381_pairing_witness_aux_batch
+struct WitnessAux {
+    uint32_t* mul_quot;  // n x (number of mul rows) x 24
+    uint8_t* carry;      // n x rows
+    uint32_t* inv_quot;  // n x 24
 };
 const WitnessProgram& witness_program();
 
@@ -59,7 +66,7 @@ class WitnessDevice {
     typedef int (*inverse_fn)(void* ctx, const uint32_t* x_dev, size_t n, uint32_t* inv_dev);
     // on_device: g1, g2 and trace are device pointers; the trace is then written in place, no staging copy
     int run(hipStream_t stream, void* ctx, inverse_fn inv, const uint64_t* g1, const uint64_t* g2, size_t n,
-            uint32_t* trace, std::string& err, bool on_device = false);
+            uint32_t* trace, std::string& err, bool on_device = false, const WitnessAux* aux = nullptr);
     void release();
 
    private:
@@ -72,6 +79,8 @@ class WitnessDevice {
     void* d_inputs_ = nullptr; size_t inputs_bytes_ = 0;
     void* d_x_ = nullptr;      size_t x_bytes_ = 0;
     void* d_g_ = nullptr;      size_t g_bytes_ = 0;
+    void* d_aux_ = nullptr;    size_t aux_bytes_ = 0;
+    uint32_t* d_mul_index_ = nullptr;
 };
 
 }  // namespace bls381

@@ -461,6 +461,21 @@ class Context:
         check(lib.bls381_pairing_witness_batch(self._h, _p64(g1), _p64(g2), n, _p32(trace)))
         return trace
 
+    def pairing_witness_aux_batch(self, g1, g2):
+        """The trace plus the gadgets' auxiliary values: (trace, mul_quot (n, mul rows, 24), carry (n, rows),
+        inv_quot (n, 24))."""
+        g1, g2 = _arr64(g1, 12), _arr64(g2, 24)
+        n = g1.shape[0]
+        if g2.shape[0] != n:
+            raise ValueError("g1 and g2 must have one row per proof")
+        rows, n_mul = lib.bls381_pairing_witness_rows(), lib.bls381_pairing_witness_mul_rows()
+        trace = np.empty((n, rows, 12), dtype=np.uint32)
+        mq = np.empty((n, n_mul, 24), dtype=np.uint32)
+        cy = np.empty((n, rows), dtype=np.uint8)
+        iq = np.empty((n, 24), dtype=np.uint32)
+        check(lib.bls381_pairing_witness_aux_batch(self._h, _p64(g1), _p64(g2), n, _p32(trace), _p32(mq), _p8(cy), _p32(iq)))
+        return trace, mq, cy, iq
+
     # ---- measurement
     def last_timing(self):
         ms = (C.c_float * 4)()

@@ -293,6 +293,25 @@ def test_pairing_witness_trace(ctx):
         assert R.myfq12_to_fq12(out) == R.native_pairing([ps[e]], [qs[e]])
 
 
+def test_pairing_witness_auxiliary_values(ctx):
+    """The gadgets' auxiliary values beside the trace (mul quotients, add/sub/neg carry bytes, the inv row's quotient)
+    against the CPU replay, which forms them from Python integers: a * b == q * p + r for every one of the 70,656
+    mul rows of two proofs.  Parity with the plonky2_ecdsa fork is unpinned (its source is not in the reference tree)."""
+    import witness_ref as W
+    ps, qs = H.random_pairs(2, 909)
+    trace, mq, cy, iq = ctx.pairing_witness_aux_batch(H.g1_array(ps), H.g2_array(qs))
+    assert mq.shape == (2, 70656, 24) and cy.shape == (2, 141376) and iq.shape == (2, 24)
+    assert np.array_equal(trace, ctx.pairing_witness_batch(H.g1_array(ps), H.g2_array(qs)))
+    for e in range(2):
+        tr, _ = W.pairing_witness(ps[e], qs[e])
+        want_q, want_c, want_i = tr.aux()
+        limbs24 = lambda v: [(v >> (32 * k)) & 0xffffffff for k in range(24)]
+        assert np.array_equal(mq[e], np.array([limbs24(q) for q in want_q], dtype=np.uint32))
+        assert np.array_equal(cy[e], np.array(want_c, dtype=np.uint8))
+        assert iq[e].tolist() == limbs24(want_i)
+        assert 0 < cy[e].sum() < 141376 and not mq[e][:, 12:].any()      # quotients are below p
+
+
 def test_fp_mul_kernel_against_big_integers(ctx):
     """The hand-scheduled Montgomery multiplier on 2^16 random pairs plus edge values (0, 1, p-1,
     R mod p, all-ones below 2p) against Python integers and against the plain-C form."""

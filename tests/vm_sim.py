@@ -126,20 +126,14 @@ def normalise(d):
 
 
 def reduce(d):
-    d = normalise(d)
+    d = list(d)
     q = (d[13] * 40323) >> 32
     c = 0
-    carry = 0
     for i in range(14):
         c += q * P28[i]
-        if i < 13:
-            t = s32(d[i] - (c & MASK) + carry)
-            d[i] = t & MASK
-            carry = t >> 28
-        else:
-            d[i] = s32(d[i] - c + carry)             # the top digit takes what is left, sign included
+        d[i] = s32(d[i] - (c & MASK if i < 13 else c))   # the top digit takes what is left, sign included
         c >>= 28
-    return d
+    return normalise(d)
 
 
 def canon(d):
@@ -239,33 +233,33 @@ def run_program(prog, gin, strict=True, extra_consts=()):
                 assert (value(out) << RBITS) % P == t % P and abs(value(out)) < 2048 * P
                 writes.append(("lds", w[0], out))
             elif typ == ST_LIN:
+                def lin(nt, B, terms, dst):
+                    B -= 16 if B >= 8 else 0
+                    assert B == 0 or mt & 0x300, "a sum around a shifted zero must be swept"
+                    acc = [B << 28] + [(B << 28) - B] * 12 + [-B]        # a digit vector of value 0
+                    assert value(acc) == 0
+                    for t in range(len(terms)):
+                        e = terms[t]
+                        v = lds[e & 0x7f]
+                        assert v is not None, "LIN reads an empty slot"
+                        coef = (e >> 7) & 0xff
+                        coef -= 256 if coef >= 128 else 0
+                        if t >= nt:
+                            assert e == zero_slot               # padding: ZERO with coefficient 0
+                            continue
+                        assert coef != 0
+                        acc = [s32(x + coef * y) for x, y in zip(acc, v)]
+                    assert abs(value(acc)) < MUL_LIMIT * P
+                    if mt & 0x200:
+                        assert all(abs(x) <= 7 << 28 for x in acc[:13]), "digit too wide for the reduction"
+                        acc = reduce(acc)                # sweeps as well
+                        assert -P < value(acc) < 2 * P
+                    elif mt & 0x100:
+                        acc = normalise(acc)
+                    writes.append(("lds", dst, acc))
                 nt = (d[0] >> 8) & 0xff
                 assert nt <= (mt & 0xff) <= 7
-                B = (d[0] >> 24) & 0xf
-                B -= 16 if B >= 8 else 0
-                assert B == 0 or mt & 0x300, "a sum around a shifted zero must be swept"
-                acc = [B << 28] + [(B << 28) - B] * 12 + [-B]        # a digit vector of value 0
-                assert value(acc) == 0
-                for t in range(mt & 0xff):
-                    e = w[1 + t]
-                    v = lds[e & 0x7f]
-                    assert v is not None, "LIN reads an empty slot"
-                    coef = (e >> 7) & 0xff
-                    coef -= 256 if coef >= 128 else 0
-                    if t >= nt:
-                        assert e == zero_slot               # padding: ZERO with coefficient 0
-                        continue
-                    assert coef != 0
-                    acc = [s32(x + coef * y) for x, y in zip(acc, v)]
-                if DEBUG and os.environ.get('VM_SIM_DEBUG') == "%d:%d" % (s, w[0]):
-                    print("LIN step", s, "dst", w[0], "mt", hex(mt), "terms", [(w[1 + t] & 0x7f, ((w[1 + t] >> 7) & 0xff), PROV.get(w[1 + t] & 0x7f), "%.2f" % (max(abs(x) for x in lds[w[1 + t] & 0x7f]) / 2 ** 28)) for t in range(nt)])
-                assert abs(value(acc)) < MUL_LIMIT * P
-                if mt & 0x200:
-                    acc = reduce(acc)                # sweeps as well
-                    assert -P < value(acc) < 2 * P
-                elif mt & 0x100:
-                    acc = normalise(acc)
-                writes.append(("lds", w[0], acc))
+                lin(nt, (d[0] >> 24) & 0xf, w[1:1 + (mt & 0xff)], w[0])
             else:
                 kind = (d[0] >> 8) & 0xff
                 if kind == CK_IN:

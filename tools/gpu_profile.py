@@ -17,7 +17,7 @@ for spec in sys.argv[1:] or ["8:0"]:
     ctx = B.Context(0, K, slots)
     progs = ("miller", "fe2")
     if os.environ.get("MICRO"):
-        progs = ("t_lin1", "t_lin2", "t_lin4", "t_lin7", "t_sweep4", "t_reduce4", "t_mul", "t_dot2", "t_dot2w2", "t_dot2w3", "t_spill", "t_fill", "t_const")
+        progs = os.environ["MICRO"].split(",") if "t_" in os.environ["MICRO"] else ("t_lin1", "t_lin2", "t_lin4", "t_lin7", "t_sweep4", "t_reduce4", "t_mul", "t_dot2", "t_dot2w2", "t_dot2w3", "t_spill", "t_fill", "t_const")
     for which in progs:
         out = (C.c_uint64 * 32)()
         if _lib.lib.bls381_debug_profile(ctx.handle, which.encode(), 65536, out) != 0:
