@@ -186,13 +186,19 @@ static Program microbench_program(const std::string& which, int K, int slots) {
     else if (which == "t_dot2") h.type = ST_DOT2;
     else if (which == "t_dot2w2") { h.type = ST_DOT2; width = 2; }
     else if (which == "t_dot2w3") { h.type = ST_DOT2; width = 3; }
+    else if (which.rfind("t_dotn", 0) == 0) { h.type = ST_DOTN; width = atoi(which.c_str() + 6); }
     else if (which == "t_spill") kind = CK_SPILL;
     else if (which == "t_fill") kind = CK_FILL;
     else if (which == "t_const") kind = CK_CONST;
     else throw std::runtime_error("unknown program " + which);
-    if (nterms < 0 || nterms > LIN_MAX_TERMS || slots < 3 * K + 2) throw std::runtime_error("bad microbenchmark " + which);
+    if (nterms < 0 || nterms > LIN_MAX_TERMS || slots < 2 * K + 2) throw std::runtime_error("bad microbenchmark " + which);
+    const int nsrc = slots >= 3 * K + 2 ? 2 * K : K;  // operand slots; the results go to the K slots after them
     if (h.type == ST_LIN) h.max_terms |= (uint32_t)nterms;
     if (h.type == ST_FMUL || h.type == ST_DOT2) h.max_terms = (uint32_t)width;
+    if (h.type == ST_DOTN) {
+        if (width < 3 || width > DOTN_MAX_PAIRS) throw std::runtime_error("bad microbenchmark " + which);
+        h.max_terms = (uint32_t)width;
+    }
     for (int s = 0; s < 1000; s++) {
         p.hdrs.push_back(h);
         for (int r = 0; r < K; r++) {
@@ -202,16 +208,23 @@ static Program microbench_program(const std::string& which, int K, int slots) {
                 d.hdr |= kind << 8;
                 d.w[0] = (uint16_t)r; d.w[1] = (uint16_t)(kind == CK_CONST ? r % C_COUNT : r);
             } else {
-                d.w[0] = (uint16_t)(2 * K + r);
+                d.w[0] = (uint16_t)(nsrc + r);
                 for (int t = 1; t <= 12; t++) d.w[t] = (uint16_t)(slots - 2);
-                if (h.type == ST_LIN) {
+                for (int t = 0; t < 4; t++) d.w[DW_DOTN_HI + t] = (uint16_t)(slots - 2);
+                if (h.type == ST_DOTN) {
+                    for (int t = 0; t < width; t++) {
+                        const int ia = t < 6 ? 1 + 2 * t : DW_DOTN_HI + 2 * (t - 6);
+                        d.w[ia] = (uint16_t)((r + 3 * t + s) % nsrc);
+                        d.w[ia + 1] = (uint16_t)(((r + 5 * t + s + 1) % nsrc) | ((t & 1) ? 0x8000 : 0));
+                    }
+                } else if (h.type == ST_LIN) {
                     d.hdr |= (uint32_t)nterms << 8;
                     for (int t = 0; t < nterms; t++)
-                        d.w[1 + t] = (uint16_t)(((r + 3 * t + s) % (2 * K)) | (((t == 1 ? -1 : 1) & 0xff) << 7));
+                        d.w[1 + t] = (uint16_t)(((r + 3 * t + s) % nsrc) | (((t == 1 ? -1 : 1) & 0xff) << 7));
                 } else {
                     for (int jo = 0; jo < (h.type == ST_DOT2 ? 4 : 2); jo++)
                         for (int t = 0; t < width; t++)
-                            d.w[1 + 3 * jo + t] = (uint16_t)(((r + 3 * jo + 5 * t + s) % (2 * K)) | ((jo == 3 && (r & 1)) ? 0x8000 : 0));
+                            d.w[1 + 3 * jo + t] = (uint16_t)(((r + 3 * jo + 5 * t + s) % nsrc) | ((jo == 3 && (r & 1)) ? 0x8000 : 0));
                     if (h.type == ST_DOT2) d.hdr |= 2u;
                 }
             }
@@ -1419,11 +1432,11 @@ extern "C" int bls381_debug_program(const char* which, int K, int lds_slots, uin
         return fail(BLS381_ERR_INVALID, e.what());
     }
     info[0] = K; info[1] = (uint32_t)p.hdrs.size(); info[2] = p.n_lds_slots; info[3] = p.n_tmp_slots;
-    info[4] = p.n_in; info[5] = p.n_out; info[6] = p.n_fmul * 300 + p.n_dot2 * 444; info[7] = p.n_lin;
+    info[4] = p.n_in; info[5] = p.n_out; info[6] = p.n_fmul * 300 + p.n_dot2 * 444 + p.n_dotn_products * 144 + p.n_dotn * 156; info[7] = p.n_lin;
     if (getenv("BLS381_SCHED_STATS"))
-        fprintf(stderr, "%s K=%d slots=%d: steps %zu (mul %d, dot2 %d [wide %d], sum %d, copy %d) ops: mul %d dot2 %d sum %d (terms %d, reducing %d, sweeping %d) copy %d tmp %d\n",
-                which, K, lds_slots, p.hdrs.size(), p.n_fmul_steps, p.n_dot2_steps, p.n_wide_mul_steps, p.n_lin_steps, p.n_copy_steps, p.n_fmul,
-                p.n_dot2, p.n_lin, p.n_lin_terms, p.n_reduce, p.n_norm, p.n_copy, p.n_tmp_slots);
+        fprintf(stderr, "%s K=%d slots=%d: steps %zu (mul %d, dot2 %d [wide %d], n-product %d, sum %d, copy %d) ops: mul %d dot2 %d n-product %d (products %d) sum %d (terms %d, reducing %d, sweeping %d) copy %d tmp %d\n",
+                which, K, lds_slots, p.hdrs.size(), p.n_fmul_steps, p.n_dot2_steps, p.n_wide_mul_steps, p.n_dotn_steps, p.n_lin_steps, p.n_copy_steps, p.n_fmul,
+                p.n_dot2, p.n_dotn, p.n_dotn_products, p.n_lin, p.n_lin_terms, p.n_reduce, p.n_norm, p.n_copy, p.n_tmp_slots);
     if (getenv("BLS381_SCHED_STATS")) fprintf(stderr, "   carried fills %d, carried spills %d\n", p.n_piggy_fill, p.n_piggy_spill);
     if (hdrs && descs) {
         if (capacity_steps < p.hdrs.size()) return fail(BLS381_ERR_INVALID, "capacity too small");

@@ -39,6 +39,24 @@ int Dag::dot2(int a, int b, int c, int d, bool neg_d) {
     nodes.push_back(n);
     return (int)nodes.size() - 1;
 }
+int Dag::dot2s(int a, int b, int sign_ab, int c, int d, int sign_cd) {
+    assert(a >= 0 && b >= 0 && c >= 0 && d >= 0);
+    Node n; n.kind = NK_DOT2;
+    n.op[0] = {Term{a, 1}}; n.op[1] = {Term{b, sign_ab < 0 ? -1 : 1}}; n.op[2] = {Term{c, 1}}; n.op[3] = {Term{d, sign_cd < 0 ? -1 : 1}};
+    nodes.push_back(n);
+    return (int)nodes.size() - 1;
+}
+int Dag::dotn(const std::vector<Product>& products) {
+    assert(!products.empty() && (int)products.size() <= DOTN_MAX_PAIRS);
+    Node n; n.kind = NK_DOTN;
+    for (auto& pr : products) {
+        assert(pr.a >= 0 && pr.b >= 0 && (pr.sign == 1 || pr.sign == -1));
+        n.pa.push_back(Term{pr.a, 1});
+        n.pb.push_back(Term{pr.b, pr.sign});
+    }
+    nodes.push_back(n);
+    return (int)nodes.size() - 1;
+}
 // equal nodes merge into one term, terms that cancel vanish
 static std::vector<Term> merge_terms(const std::vector<Term>& in) {
     std::vector<Term> out;
@@ -81,6 +99,8 @@ void Dag::store_out(int node, int slot) {
 
 static inline int n_operands(const Node& n) { return n.kind == NK_DOT2 ? 4 : (n.kind == NK_FMUL ? 2 : 0); }
 static inline bool is_mul(const Node& n) { return n.kind == NK_FMUL || n.kind == NK_DOT2; }
+// anything that ends in a Montgomery reduction: its result has normalised digits and a value bound of its own
+static inline bool is_product(const Node& n) { return is_mul(n) || n.kind == NK_DOTN; }
 
 static void for_each_src(const Node& n, const std::function<void(int)>& f) {
     switch (n.kind) {
@@ -89,6 +109,10 @@ static void for_each_src(const Node& n, const std::function<void(int)>& f) {
             for (int j = 0; j < n_operands(n); j++) for (auto& t : n.op[j]) f(t.node);
             break;
         case NK_LIN: for (auto& t : n.terms) f(t.node); break;
+        case NK_DOTN:
+            for (auto& t : n.pa) f(t.node);
+            for (auto& t : n.pb) f(t.node);
+            break;
         case NK_STOREOUT: f(n.a); break;
         default: break;
     }
@@ -108,6 +132,8 @@ static void drop_dead_nodes(std::vector<Node>& nodes) {
         Node nd = nodes[i];
         for (int j = 0; j < 4; j++) for (auto& t : nd.op[j]) t.node = remap[t.node];
         for (auto& t : nd.terms) t.node = remap[t.node];
+        for (auto& t : nd.pa) t.node = remap[t.node];
+        for (auto& t : nd.pb) t.node = remap[t.node];
         if (nd.kind == NK_STOREOUT) nd.a = remap[nd.a];
         remap[i] = (int)out.size();
         out.push_back(nd);
@@ -225,9 +251,10 @@ void Dag::optimise() {
 // ------------------------------------------------------------------------------- scheduler
 namespace {
 
-enum OpClass { OC_FMUL = 0, OC_LIN = 1, OC_COPY = 2, OC_DOT2 = 3 };
+enum OpClass { OC_FMUL = 0, OC_LIN = 1, OC_COPY = 2, OC_DOTN = 3 };
 inline OpClass class_of(NodeKind k) {
     if (k == NK_FMUL || k == NK_DOT2) return OC_FMUL;  // one multiplier class; see ST_DOT2
+    if (k == NK_DOTN) return OC_DOTN;
     if (k == NK_LIN) return OC_LIN;
     return OC_COPY;
 }
@@ -264,6 +291,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
     std::vector<int> prio(n, 0);
     for (int i = n - 1; i >= 0; i--) {
         int w = N[i].kind == NK_FMUL ? 7 : (N[i].kind == NK_DOT2 ? 9 : (N[i].kind == NK_LIN ? 2 : 1));
+        if (N[i].kind == NK_DOTN) w = 5 + 2 * (int)N[i].pa.size();
         int best = 0;
         for (int s : succ[i]) best = std::max(best, prio[s]);
         prio[i] = best + w;
@@ -295,7 +323,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         int best = -1;
         for (int x : cands) {
             const bool sum_ok = N[x].kind == NK_LIN && !done_flag[x] && !lin_reduce[x];
-            const bool mul_ok = is_mul(N[x]) && !narrow[x] && bnd[x] > 2 && &bnd == &vb;
+            const bool mul_ok = is_product(N[x]) && !narrow[x] && bnd[x] > 2 && &bnd == &vb;
             if ((sum_ok || mul_ok) && (best < 0 || bnd[x] > bnd[best])) best = x;
         }
         if (best < 0) {
@@ -357,6 +385,23 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                     vb[i] = 1 + (int)((sv + 2519) / 2520); dlo[i] = 0; dhi[i] = 1;
                     break;
                 }
+                case NK_DOTN: {
+                    std::vector<int> ops;
+                    long sv = 0;
+                    int sd = 0;
+                    bool too_wide = false;
+                    for (size_t t = 0; t < nd.pa.size(); t++) {
+                        const int a = nd.pa[t].node, b = nd.pb[t].node;
+                        sv += (long)vb[a] * vb[b];
+                        sd += dmag[a] * dmag[b];
+                        too_wide |= vb[a] > SUM_VB_LIMIT || vb[b] > SUM_VB_LIMIT;
+                        ops.push_back(a); ops.push_back(b);
+                    }
+                    if (sv > (narrow[i] ? 2500L : MUL_VB_LIMIT) || too_wide) treated(widest(ops, vb, lin_reduce), lin_reduce, n_reduce);
+                    else if (sd > MUL_DB_LIMIT) treated(widest(ops, dmag, lin_norm), lin_norm, n_norm);
+                    vb[i] = 1 + (int)((sv + 2519) / 2520); dlo[i] = 0; dhi[i] = 1;
+                    break;
+                }
                 case NK_LIN: {
                     const SumBound b = sum_bound(nd.terms);
                     std::vector<int> ops;
@@ -390,7 +435,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                 }
                 case NK_STOREOUT:
                     // a store handles (-p, 2p) with normalised digits: what multiplications produce
-                    if (!is_mul(N[nd.a]))
+                    if (!is_product(N[nd.a]))
                         throw std::runtime_error("scheduler: stored value must come from a multiplication");
                     if (vb[nd.a] > 2 && !narrow[nd.a]) { narrow[nd.a] = 1; redo = nd.a; }
                     break;
@@ -420,6 +465,10 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
             if (is_mul(nd)) {
                 int sd = 0;
                 for (int j = 0; j < n_operands(nd); j += 2) sd += sum_bound(nd.op[j]).mag * sum_bound(nd.op[j + 1]).mag;
+                if (sd > MUL_DB_LIMIT) fprintf(stderr, "verify: node %d product magnitudes %d\n", i, sd);
+            } else if (nd.kind == NK_DOTN) {
+                int sd = 0;
+                for (size_t t = 0; t < nd.pa.size(); t++) sd += dmag[nd.pa[t].node] * dmag[nd.pb[t].node];
                 if (sd > MUL_DB_LIMIT) fprintf(stderr, "verify: node %d product magnitudes %d\n", i, sd);
             } else if (nd.kind == NK_LIN) {
                 const SumBound b = sum_bound(nd.terms);
@@ -471,10 +520,13 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         int cls;
         // full multiplier steps first, then sums and copies (which unlock more multiplications),
         // then partial multiplier steps
-        if ((int)cand[OC_FMUL].size() >= K) cls = OC_FMUL;
+        if ((int)cand[OC_DOTN].size() >= K) cls = OC_DOTN;
+        else if ((int)cand[OC_FMUL].size() >= K) cls = OC_FMUL;
         else if (!cand[OC_LIN].empty()) cls = OC_LIN;
         else if (!cand[OC_COPY].empty()) cls = OC_COPY;
+        else if (cand[OC_DOTN].size() >= cand[OC_FMUL].size() && !cand[OC_DOTN].empty()) cls = OC_DOTN;
         else if (!cand[OC_FMUL].empty()) cls = OC_FMUL;
+        else if (!cand[OC_DOTN].empty()) cls = OC_DOTN;
         else throw std::runtime_error("scheduler: no candidate");
         auto& c = cand[cls];
         std::sort(c.begin(), c.end(), [&](int a, int b) {
@@ -495,6 +547,13 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
             const int lead_w = mul_shape(N[c[0]]).width;
             std::stable_sort(c.begin() + 1, c.end(), [&](int a, int b) {
                 return std::abs(mul_shape(N[a]).width - lead_w) < std::abs(mul_shape(N[b]).width - lead_w);
+            });
+        }
+        if ((int)c.size() > K && cls == OC_DOTN) {
+            // every lane of the step multiplies as many products as its largest op: group by product count
+            const int lead_n = (int)N[c[0]].pa.size();
+            std::stable_sort(c.begin() + 1, c.end(), [&](int a, int b) {
+                return std::abs((int)N[a].pa.size() - lead_n) < std::abs((int)N[b].pa.size() - lead_n);
             });
         }
         if ((int)c.size() > K) {
@@ -711,13 +770,15 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         }
         // a step holding a two-product op runs the two-product multiplier on every lane; single
         // products in it use zero for the second product
-        h.type = st.cls == OC_FMUL ? (any_dot2 ? ST_DOT2 : ST_FMUL) : (st.cls == OC_LIN ? ST_LIN : ST_COPY);
+        h.type = st.cls == OC_FMUL ? (any_dot2 ? ST_DOT2 : ST_FMUL) : (st.cls == OC_LIN ? ST_LIN : (st.cls == OC_DOTN ? ST_DOTN : ST_COPY));
+        if (st.cls == OC_DOTN) h.max_terms = 3;  // the kernel multiplies at least three products
         if (st.cls == OC_FMUL) h.max_terms = (uint32_t)mul_width;
         for (int r = 0; r < K; r++) {
             OpDesc d; std::memset(&d, 0, sizeof d);
             if (st.cls != OC_COPY) {  // idle lane / padding defaults
                 d.w[0] = (uint16_t)TRASH_SLOT;
                 for (int t = 1; t <= 12; t++) d.w[t] = (uint16_t)ZERO_SLOT;
+                if (st.cls == OC_DOTN) for (int t = 0; t < 4; t++) d.w[DW_DOTN_HI + t] = (uint16_t)ZERO_SLOT;
                 if (r < (int)cur_spills.size()) {
                     d.w[DW_SPILL] = (uint16_t)(cur_spills[r].first | 0x8000); d.w[DW_SPILL + 1] = (uint16_t)cur_spills[r].second;
                     P.n_piggy_spill++;
@@ -755,6 +816,19 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                                 d.w[1 + 3 * j + t] = (uint16_t)(src_slot[terms[t].node] | (neg ? 0x8000 : 0));
                             }
                         }
+                        break;
+                    }
+                    case NK_DOTN: {
+                        const int np = (int)nd.pa.size();
+                        assert(np >= 1 && np <= DOTN_MAX_PAIRS);
+                        d.w[0] = (uint16_t)dst_slot[op];
+                        for (int t = 0; t < np; t++) {
+                            const int ia = t < 6 ? 1 + 2 * t : DW_DOTN_HI + 2 * (t - 6);
+                            d.w[ia] = (uint16_t)src_slot[nd.pa[t].node];
+                            d.w[ia + 1] = (uint16_t)(src_slot[nd.pb[t].node] | (nd.pb[t].coef < 0 ? 0x8000 : 0));
+                        }
+                        h.max_terms = std::max<uint32_t>(h.max_terms, np);
+                        P.n_dotn++; P.n_dotn_products += np;
                         break;
                     }
                     case NK_LIN: {
@@ -799,6 +873,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         if (st.cls == OC_FMUL && any_dot2) P.n_dot2_steps++;
         else if (st.cls == OC_FMUL) P.n_fmul_steps++;
         else if (st.cls == OC_LIN) P.n_lin_steps++;
+        else if (st.cls == OC_DOTN) P.n_dotn_steps++;
         else P.n_copy_steps++;
         // values produced but never read (cannot happen after DCE) would leak a slot; guard anyway
         for (int op : st.ops)

@@ -12,7 +12,7 @@
 
 namespace bls381 {
 
-enum NodeKind : uint8_t { NK_FMUL, NK_LIN, NK_LOADIN, NK_LOADC, NK_STOREOUT, NK_DOT2 };
+enum NodeKind : uint8_t { NK_FMUL, NK_LIN, NK_LOADIN, NK_LOADC, NK_STOREOUT, NK_DOT2, NK_DOTN };
 
 struct Term {
     int node;
@@ -27,6 +27,14 @@ struct Node {
     int a = -1;               // STOREOUT source
     int idx = -1;             // LOADIN: gin slot, LOADC: constant id, STOREOUT: gout slot
     std::vector<Term> terms;  // LIN: sum of coef * node
+    // DOTN: sum over t of pa[t] * pb[t], subtracted where pb[t].coef = -1 (pa's coefficients are 1): up to
+    // DOTN_MAX_PAIRS products of plain values under one reduction
+    std::vector<Term> pa, pb;
+};
+
+struct Product {
+    int a, b;
+    int sign;  // +1 or -1
 };
 
 class Dag {
@@ -38,6 +46,8 @@ class Dag {
     int load_const(int cid);
     int fmul(int a, int b);
     int dot2(int a, int b, int c, int d, bool neg_d = false);  // a*b + c*d, or a*b - c*d
+    int dot2s(int a, int b, int sign_ab, int c, int d, int sign_cd);  // +-a*b +- c*d
+    int dotn(const std::vector<Product>& products);              // sum of signed products, one reduction
     int lin(std::vector<Term> terms);
     void store_out(int node, int slot);
 
@@ -61,6 +71,7 @@ struct Program {
     int n_piggy_fill = 0, n_piggy_spill = 0;  // copies riding on compute steps
     int n_reduce = 0, n_norm = 0;  // sums followed by a reduction / by a carry sweep only
     int n_wide_mul_steps = 0;      // multiplier steps with more than one term in some operand
+    int n_dotn = 0, n_dotn_products = 0, n_dotn_steps = 0;  // n-product ops, their products, their steps
 };
 
 // Schedules `dag` for groups of K lanes with at most `lds_slots` LDS slots per group.

@@ -6,6 +6,7 @@
 #pragma once
 #include <cstdint>
 #include <initializer_list>
+#include <map>
 #include <utility>
 #include <vector>
 
@@ -22,12 +23,20 @@ static const SFp SZERO{-1};
 static const SFp SONE{-2};
 
 struct SFq2 { SFp c0, c1; };
+
+// Unreduced values: a signed sum of products of Fp values, not yet multiplied out.  Sums, differences and
+// multiples of xi of such values only edit the list; Tower::reduce turns a list into one n-product
+// operation with a single reduction (or several and a sum when it is longer than an operation holds).
+struct UTerm { int a, b, coef; };  // coef * node a * node b
+struct UFp { std::vector<UTerm> t; };
+struct UFq2 { UFp c0, c1; };
+struct UFq6 { UFq2 c0, c1, c2; };
 struct SFq6 { SFq2 c0, c1, c2; };
 struct SFq12 { SFq6 c0, c1; };
 
 class Tower {
    public:
-    explicit Tower(Dag& d) : d_(d) {}
+    explicit Tower(Dag& d);
     Dag& dag() { return d_; }
 
     // ---- Fp
@@ -62,6 +71,18 @@ class Tower {
     SFq2 mul_fp(const SFq2& a, SFp s) { return {mul(a.c0, s), mul(a.c1, s)}; }
     // sum of signed Fq2 terms as one LIN per component
     SFq2 lin2(const std::vector<std::pair<SFq2, int>>& terms);
+
+    // ---- unreduced products (see UFp)
+    UFp uadd(const UFp& a, const UFp& b, int sign_b = 1);
+    UFq2 uadd(const UFq2& a, const UFq2& b) { return {uadd(a.c0, b.c0), uadd(a.c1, b.c1)}; }
+    UFq2 umul_xi(const UFq2& a) { return {uadd(a.c0, a.c1, -1), uadd(a.c0, a.c1)}; }  // * (1+u)
+    UFq2 umul(const SFq2& a, const SFq2& b);   // the four products of the components, zero components dropped
+    UFq6 umul(const SFq6& a, const SFq6& b);   // schoolbook over umul
+    UFq6 uadd(const UFq6& a, const UFq6& b) { return {uadd(a.c0, b.c0), uadd(a.c1, b.c1), uadd(a.c2, b.c2)}; }
+    UFq6 umul_v(const UFq6& a) { return {umul_xi(a.c2), a.c0, a.c1}; }
+    SFp reduce(const UFp& u);
+    SFq2 reduce(const UFq2& u) { return {reduce(u.c0), reduce(u.c1)}; }
+    SFq6 reduce(const UFq6& u) { return {reduce(u.c0), reduce(u.c1), reduce(u.c2)}; }
 
     // ---- Fq6
     SFq6 zero6() { return {zero2(), zero2(), zero2()}; }
@@ -108,6 +129,8 @@ class Tower {
 
    private:
     Dag& d_;
+    bool lazy_;  // Fq6 products as n-product operations (schoolbook, one reduction per component)
+    std::map<std::vector<std::pair<int, int>>, int> shared_sums_;  // sums made for merged products, by their terms
 };
 
 }  // namespace bls381

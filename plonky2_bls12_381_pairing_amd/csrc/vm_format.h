@@ -18,6 +18,7 @@ enum StepType : uint32_t {
     ST_LIN  = 1,  // dst = sum_i k_i * t_i            (digit-wise, small integer k_i, no carries unless a step flag asks)
     ST_COPY = 2,  // LDS <-> global slot arrays, constant table -> LDS
     ST_DOT2 = 3,  // dst = (a * b + c * d) / 2^392    (one Montgomery reduction, in (-p, 2p)); operands as for ST_FMUL
+    ST_DOTN = 4,  // dst = (sum of +-a_t * b_t) / 2^392, t < n <= 8 (one reduction); every operand one slot
 };
 
 enum CopyKind : uint32_t {
@@ -32,6 +33,7 @@ struct StepHdr {
     uint32_t type;       // StepType
     uint32_t max_terms;  // bits 0..7: ST_LIN: largest term count among the step's ops (<= 7);
                          //            multiplier steps: largest number of terms in any operand (1..3)
+                         //            ST_DOTN: largest number of products among the step's ops (3..8)
                          // ST_LIN: bit 8: results get a carry sweep (digits back below 2^28)
                          //         bit 9: results are also brought into (-0.2p, 1.2p): quotient
                          //                estimate from the top digit
@@ -51,6 +53,9 @@ struct StepHdr {
 //                    is w[1 + 3 j + t] = slot | (negate << 15), missing terms are the ZERO slot.  The result is
 //                    a * b (+ c * d): a difference of products is expressed through the signs of d's terms.  In a
 //                    step whose header says one term per operand only d's sign is honoured.
+//   ST_DOTN        : product t is w[1 + 2 t] * w[2 + 2 t] for t < 6 and w[17 + 2 (t - 6)] * w[18 + 2 (t - 6)] for t = 6, 7
+//                    (the words between hold the carried copies): slot, and on the second factor negate << 15;
+//                    missing products are ZERO * ZERO
 //   ST_LIN         : w[1 + i] = slot | ((coefficient & 0xff) << 7), i < term count <= 7; coefficients are
 //                    signed 8-bit integers, never zero
 //   ST_COPY        : w[1] = source slot (LDS slot, global slot or constant id)
@@ -65,9 +70,9 @@ struct OpDesc {
     uint16_t w[22];
 };
 static_assert(sizeof(OpDesc) == 48, "OpDesc must be 48 bytes");
-enum { OPDESC_U32 = 12, DW_FILL = 13, DW_SPILL = 15 };
+enum { OPDESC_U32 = 12, DW_FILL = 13, DW_SPILL = 15, DW_DOTN_HI = 17 };
 
-enum { LIN_MAX_TERMS = 7, MUL_MAX_TERMS = 3, LIN_MAX_COEF = 127, MAX_LDS_SLOTS = 128 };
+enum { LIN_MAX_TERMS = 7, MUL_MAX_TERMS = 3, DOTN_MAX_PAIRS = 8, LIN_MAX_COEF = 127, MAX_LDS_SLOTS = 128 };
 
 // ---- device encoding.  The interpreter reads 32-byte descriptors, 64 per 2 KiB block, as two planes of
 // 64 x 16 bytes (words 0..3 of every descriptor, then words 4..7): a block holds floor(64 / K)
@@ -75,15 +80,17 @@ enum { LIN_MAX_TERMS = 7, MUL_MAX_TERMS = 3, LIN_MAX_COEF = 127, MAX_LDS_SLOTS =
 // so two 16-byte loads per lane fetch a whole block for a wave and the lanes then pick their
 // descriptors out of each other's registers.  The step-wide fields are replicated into every
 // descriptor of the step:
-//   w[0] bit 0 active, bit 1 second product, bit 2 unused, bits 3..4 StepType,
+//   w[0] bit 0 active, bit 1 second product, bits 3..4 and 2 StepType (bit 2 = its bit 2),
 //        bits 5..7 the step's largest term count (sums: terms of an op; multiplier steps: terms of an operand;
-//        copy steps: the CopyKind), bits 8..9 sweep / reduce flags of the step,
+//        ST_DOTN: products of an op, minus one; copy steps: the CopyKind), bits 8..9 sweep / reduce flags of the step,
 //        bit 10 the step reads w[3], bit 11 the step reads w[4], sums: bits 12..15 the shifted zero B (signed),
 //        bits 16..31 destination slot
 //        (multiplier and sum steps: destination in bits 16..22, bit 23 some lane of the step
 //        carries a fill, bit 24 some lane carries a spill)
 //   multiplier steps: w[1 + t], t = 0..2: term t of the operands a, b, c, d in bytes 0..3: LDS slot in bits 0..6,
 //        negate in bit 7
+//   ST_DOTN: w[1 + t / 2], half t % 2: product t: first factor's slot in bits 0..6, second factor's in bits 8..14,
+//        negate in bit 15
 //   sum steps: w[1 + i / 2], half i % 2: term i: LDS slot in bits 0..6, coefficient in bits 7..14
 //   copy steps: w[1] = source slot
 //   w[5] carried copies: bits 0..6 fill LDS slot, 7..8 CopyKind, 9..18 source slot, 19 valid;
@@ -94,19 +101,25 @@ struct PackedDesc {
 inline PackedDesc pack_desc(const StepHdr& h, const OpDesc& d) {
     PackedDesc p{{0, 0, 0, 0, 0, 0, 0, 0}};
     const uint32_t nterms_step = h.max_terms & 0xffu, flags = (h.max_terms >> 8) & 3u;
-    p.w[0] = (d.hdr & 3u) | (h.type << 3) | (nterms_step << 5) | (flags << 8) | ((uint32_t)d.w[0] << 16);
+    p.w[0] = (d.hdr & 3u) | ((h.type & 3u) << 3) | (h.type & 4u) | ((h.type == ST_DOTN ? nterms_step - 1 : nterms_step) << 5) | (flags << 8) |
+             ((uint32_t)d.w[0] << 16);
     if (h.type == ST_COPY) {
         p.w[0] |= ((d.hdr >> 8) & 7u) << 5;  // (the term-count field is the copy kind here)
         p.w[1] = d.w[1];
     } else {
         // which of the words beyond w[2] the step's lanes have to fetch
-        if (h.type == ST_LIN ? nterms_step > 4 : nterms_step > 2) p.w[0] |= 1u << 10;
-        if (h.type == ST_LIN && nterms_step > 6) p.w[0] |= 1u << 11;
+        if (h.type == ST_LIN || h.type == ST_DOTN ? nterms_step > 4 : nterms_step > 2) p.w[0] |= 1u << 10;
+        if ((h.type == ST_LIN || h.type == ST_DOTN) && nterms_step > 6) p.w[0] |= 1u << 11;
         p.w[0] |= ((h.max_terms >> 16) & 3u) << 23;
         if (h.type == ST_LIN) {
             const uint32_t B = (d.hdr >> 24) & 0xfu;
             p.w[0] |= B << 12;
             for (int i = 0; i < LIN_MAX_TERMS; i++) p.w[1 + i / 2] |= (uint32_t)(d.w[1 + i] & 0x7fffu) << (16 * (i % 2));
+        } else if (h.type == ST_DOTN) {
+            for (int t = 0; t < DOTN_MAX_PAIRS; t++) {
+                const uint16_t a = d.w[t < 6 ? 1 + 2 * t : DW_DOTN_HI + 2 * (t - 6)], b = d.w[t < 6 ? 2 + 2 * t : DW_DOTN_HI + 1 + 2 * (t - 6)];
+                p.w[1 + t / 2] |= (uint32_t)((a & 0x7fu) | ((b & 0x7fu) << 8) | ((b & 0x8000u) ? 0x8000u : 0u)) << (16 * (t % 2));
+            }
         } else {
             for (int j = 0; j < 4; j++)
                 for (int t = 0; t < MUL_MAX_TERMS; t++) {

@@ -52,7 +52,8 @@ __host__ __device__ inline size_t vm_lds_bytes(int lds_slots, int K) {
 // TAG only gives the Miller-loop, final-exponentiation and auxiliary launches distinct kernel
 // names in profiler output; the code is identical.  TAG_PROFILE additionally has the first lane of
 // the grid add the shader-clock cycles of every step to A.prof, by step kind: 0 product, 1 sum,
-// 2 sum + carry sweep, 3 two-product, 4 + CopyKind copies, 9 sum + reduction, 10 multiplier step with summed operands.
+// 2 sum + carry sweep, 3 two-product, 4 + CopyKind copies, 9 sum + reduction, 10 multiplier step with summed operands,
+// 11 n-product step.
 enum { TAG_MILLER = 0, TAG_FINAL_EXP = 1, TAG_AUX = 2, TAG_PROFILE = 3 };
 
 template <int K, int TAG>
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
         }
         const int self = (j * K + role) * 4;
         const u32 hx = (u32)__builtin_amdgcn_readfirstlane((int)dx);  // step-wide fields
-        const u32 type = (hx >> 3) & 3u, max_terms = (hx >> 5) & 7u, flags = (hx >> 8) & 3u;
+        const u32 type = ((hx >> 3) & 3u) | (hx & 4u), max_terms = (hx >> 5) & 7u, flags = (hx >> 8) & 3u;
         if (TAG == TAG_PROFILE && tid == 0 && blockIdx.x == 0) {
             const long long now = clock64();
             if (k_prev >= 0) {
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             }
             t_prev = now;
             k_prev = type == ST_COPY ? 4 + (int)max_terms
-                                     : (type == ST_LIN ? (flags & 2u ? 9 : (flags ? 2 : 1)) : (max_terms > 1 ? 10 : (int)type));
+                                     : (type == ST_LIN ? (flags & 2u ? 9 : (flags ? 2 : 1)) : (type == ST_DOTN ? 11 : (max_terms > 1 ? 10 : (int)type)));
         }
         const bool on = lane_on && (dx & 1u);
         const u32 dst = type == ST_COPY ? dx >> 16 : (dx >> 16) & 0x7fu;
@@ -247,6 +248,57 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             for (int i = 0; i < D28; i++) r[i] = (u32)acc[i];
             if (flags & 2u) reduce28(r);  // sweeps as well
             else if (flags) normalise28(r);
+            lds_store(dst, r);
+        } else if (type == ST_DOTN) {
+            // dst = (sum over t of a_t * (+-b_t)) / 2^392 with one reduction.  Operand scanning: every product of
+            // two digits goes to its column's 64-bit accumulator; the operands of product t + 1 are loaded while
+            // product t is multiplied.  Ops with fewer products than the step's largest count are padded with
+            // ZERO * ZERO.  The columns hold up to 8 x 14 products of normalised digits plus the reduction's.
+            const int npairs = (int)max_terms + 1;  // uniform, 3..8
+            auto PAIR = [&](int t) -> u32 { return ((t < 2 ? dy : (t < 4 ? dz : (t < 6 ? d3 : d4))) >> ((t & 1) * 16)) & 0xffffu; };
+            int64_t col[2 * D28];
+#pragma unroll
+            for (int i = 0; i < 2 * D28; i++) col[i] = 0;
+            u32 pa[2][D28], pb[2][D28];
+            lds_load(PAIR(0) & 0x7fu, pa[0]);
+            lds_load((PAIR(0) >> 8) & 0x7fu, pb[0]);
+            // (written out product by product: a loop over t would index the operand registers dynamically)
+#define BLS381_PRODUCT(t)                                                                              \
+    {                                                                                                  \
+        if ((t) + 1 < DOTN_MAX_PAIRS && ((t) < 2 || (t) + 1 < npairs)) {                               \
+            lds_load(PAIR((t) + 1) & 0x7fu, pa[((t) + 1) & 1]);                                        \
+            lds_load((PAIR((t) + 1) >> 8) & 0x7fu, pb[((t) + 1) & 1]);                                 \
+        }                                                                                              \
+        const u32 m = (u32)((int)(PAIR(t) << 16) >> 31); /* bit 15: the product is subtracted */      \
+        u32 nb[D28];                                                                                   \
+        xor_add28_first(nb, pb[(t) & 1], m, m & 1u);                                                   \
+        _Pragma("unroll") for (int i = 0; i < D28; i++)                                                \
+            _Pragma("unroll") for (int j = 0; j < D28; j++) col[i + j] += (int64_t)(int)pa[(t) & 1][i] * (int)nb[j]; \
+    }
+            BLS381_PRODUCT(0) BLS381_PRODUCT(1) BLS381_PRODUCT(2)
+            if (npairs > 3) { BLS381_PRODUCT(3)
+                if (npairs > 4) { BLS381_PRODUCT(4)
+                    if (npairs > 5) { BLS381_PRODUCT(5)
+                        if (npairs > 6) { BLS381_PRODUCT(6)
+                            if (npairs > 7) { BLS381_PRODUCT(7) } } } } }
+#undef BLS381_PRODUCT
+            // Montgomery reduction column by column: q = -col / p mod 2^28 clears the column's low 28 bits, the
+            // rest moves up
+            const u32 P28[D28] = BLS381_P28_DIGITS;
+            u32 r[D28];
+#pragma unroll
+            for (int k = 0; k < D28; k++) {
+                const u32 q = ((u32)col[k] * BLS381_N28_DEV) & BLS381_MASK28;
+#pragma unroll
+                for (int j = 0; j < D28; j++) col[k + j] += (int64_t)((u64)q * P28[j]);
+                col[k + 1] += col[k] >> 28;
+            }
+#pragma unroll
+            for (int k = D28; k < 2 * D28 - 1; k++) {
+                r[k - D28] = (u32)col[k] & BLS381_MASK28;
+                col[k + 1] += col[k] >> 28;
+            }
+            r[D28 - 1] = (u32)col[2 * D28 - 1];
             lds_store(dst, r);
         } else if (type == ST_DOT2 || type == ST_FMUL) {
             // operands: a, b (, c, d), each a signed sum of up to max_terms slots added up as they are loaded

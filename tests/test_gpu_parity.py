@@ -472,6 +472,26 @@ def test_other_lane_group_geometries(lanes, slots):
         prep.close()
 
 
+@pytest.mark.parametrize("lanes", [6, 8])
+def test_lazy_product_programs(lanes, monkeypatch):
+    """The programs built from n-product operations (BLS381_LAZY_PRODUCTS=1: schoolbook Fq6 products and line products,
+    one reduction per component) give the same pairings, Miller values and Fq12 products, bit for bit."""
+    import plonky2_bls12_381_pairing_amd as B
+    ps, qs = H.random_pairs(70, 7700 + lanes)
+    g1, g2 = H.g1_array(ps), H.g2_array(qs)
+    with B.Context(0, lanes, 0) as c:
+        want, want_ml = c.pairing_batch(g1, g2), c.miller_loop_batch(g1, g2)
+    monkeypatch.setenv("BLS381_LAZY_PRODUCTS", "1")
+    with B.Context(0, lanes, 0) as c:
+        assert np.array_equal(c.pairing_batch(g1, g2), want)
+        assert np.array_equal(c.miller_loop_batch(g1, g2), want_ml)
+        prod = c.fq12_mul_batch(want[:35], want[35:])
+        for i in (0, 17, 34):
+            assert H.fq12_from_row(prod[i]) == R.fq12_mul(H.fq12_from_row(want[i]), H.fq12_from_row(want[35 + i]))
+    for i in (0, 69):
+        assert H.fq12_from_row(want[i]) == R.native_pairing([ps[i]], [qs[i]])
+
+
 def _bytes_array(encodings):
     return np.frombuffer(b"".join(encodings), dtype=np.uint8).reshape(len(encodings), -1)
 

@@ -163,10 +163,28 @@ def test_two_pair_miller_program():
     assert prog["n_fmul"] < 1.8 * single["n_fmul"]
 
 
+def test_lazy_product_programs(monkeypatch):
+    """The same pairing through the programs built from n-product operations (schoolbook Fq6 products, one reduction
+    per component; BLS381_LAZY_PRODUCTS=1), at 6 and 8 lanes per pairing, in the big-integer interpreter."""
+    monkeypatch.setenv("BLS381_LAZY_PRODUCTS", "1")
+    ps, qs = H.random_pairs(1, 4242)
+    p, q = ps[0], qs[0]
+    gin = [M(p[0]), M(p[1]), M(q[0][0]), M(q[0][1]), M(q[1][0]), M(q[1][1])]
+    want = R.multi_miller_loop([p], [q])
+    for K in (6, 8):
+        prog = S.get_program("miller", K, 0)
+        steps = [prog["hdrs"][2 * s] for s in range(prog["nsteps"])]
+        assert steps.count(S.ST_DOTN) > 100
+        out = S.run_program(prog, gin)
+        assert R.fq12_from_flat_ark([F(x) for x in out]) == want
+    monkeypatch.delenv("BLS381_LAZY_PRODUCTS")
+    assert S.ST_DOTN not in [S.get_program("miller", 8, 0)["hdrs"][2 * s] for s in range(50)]
+
+
 def test_program_statistics():
     """Multiplier work, counted in the work model's unit (12-limb multiply-accumulates: 300 per product,
-    444 per two-product sum with its single reduction), stays within 2% of the reference work model
-    (7,141 / 8,119 Fp multiplications x 300)."""
+    444 per two-product sum with its single reduction, 144 n + 156 per n-product sum), stays within 2% of the
+    reference work model (7,141 / 8,119 Fp multiplications x 300)."""
     p = S.get_program("miller", 8, 0)
     assert 0.7 * 7141 * 300 < p["n_fmul"] <= 1.02 * 7141 * 300
     assert S.get_program("fe2", 8, 0)["n_fmul"] <= 8119 * 300

@@ -16,7 +16,7 @@ P = R.P
 RBITS = 392                       # the interpreter's Montgomery factor: 14 digits of 28 bits
 PINV = pow(P, -1, 1 << RBITS)
 MUL_LIMIT = (1 << RBITS) // P     # 2520: operand-bound products a multiplication tolerates
-ST_FMUL, ST_LIN, ST_COPY, ST_DOT2 = 0, 1, 2, 3
+ST_FMUL, ST_LIN, ST_COPY, ST_DOT2, ST_DOTN = 0, 1, 2, 3, 4
 CK_IN, CK_FILL, CK_CONST, CK_SPILL, CK_OUT = range(5)
 N_CONST = 21
 DEBUG = bool(os.environ.get('VM_SIM_DEBUG'))
@@ -195,6 +195,8 @@ def run_program(prog, gin, strict=True, extra_consts=()):
             if not (d[0] & 1):
                 if typ != ST_COPY:  # idle lanes run branch-free on ZERO and store to TRASH
                     assert w[0] == prog["lds_slots"] - 1 and all(x == zero_slot for x in w[1:13])
+                    if typ == ST_DOTN:
+                        assert all(x == zero_slot for x in w[17:21])
                 continue
             if typ in (ST_FMUL, ST_DOT2):
                 width = mt & 0xff
@@ -231,6 +233,30 @@ def run_program(prog, gin, strict=True, extra_consts=()):
                 t = value(ops[0]) * value(ops[1]) + (value(ops[2]) * value(ops[3]) if nops == 4 else 0)
                 out = mulacc(*ops)
                 assert (value(out) << RBITS) % P == t % P and abs(value(out)) < 2048 * P
+                writes.append(("lds", w[0], out))
+            elif typ == ST_DOTN:
+                npairs = mt & 0xff
+                assert 3 <= npairs <= 8
+                idx = [1 + 2 * t if t < 6 else 17 + 2 * (t - 6) for t in range(8)]
+                t_val, worst, n_real = 0, 14 * MASK * MASK + (1 << 36), 0
+                for t in range(8):
+                    ea, eb = w[idx[t]], w[idx[t] + 1]
+                    if t >= npairs:
+                        assert ea == zero_slot and eb == zero_slot, "product beyond the step's count"
+                        continue
+                    assert not ea & 0x8000
+                    a, b = lds[ea & 0x7f], lds[eb & 0x7f]
+                    assert a is not None and b is not None, "multiplier reads an empty slot"
+                    assert abs(value(a)) < 2048 * P and abs(value(b)) < 2048 * P, "multiplier operand too wide"
+                    worst += 14 * max(abs(x) for x in a) * max(abs(x) for x in b)
+                    t_val += -value(a) * value(b) if eb & 0x8000 else value(a) * value(b)
+                    n_real += (ea != zero_slot)
+                assert worst < 1 << 63, "column accumulator leaves 64 bits"
+                assert n_real >= 1
+                m = (-t_val * PINV) % (1 << RBITS)
+                rr = (t_val + m * P) >> RBITS
+                assert abs(rr) < 2048 * P
+                out = [(rr >> (28 * i)) & MASK for i in range(13)] + [s32(rr >> (28 * 13))]
                 writes.append(("lds", w[0], out))
             elif typ == ST_LIN:
                 def lin(nt, B, terms, dst):

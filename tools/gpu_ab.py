@@ -20,7 +20,7 @@ import plonky2_bls12_381_pairing_amd as B
 ps, qs = random_pairs(6, 3)
 n = 65536
 g1 = np.tile(g1_array(ps), (n // 6 + 1, 1))[:n]; g2 = np.tile(g2_array(qs), (n // 6 + 1, 1))[:n]
-ctx = B.Context(0)
+ctx = B.Context(0, int(os.environ.get("AB_K", "0")), int(os.environ.get("AB_SLOTS", "0")))
 for rep in range(6):
     ctx.pairing_batch(g1, g2); ms = ctx.last_timing()
     if rep: print("T", ms[0], ms[2], flush=True)

@@ -11,7 +11,7 @@ import plonky2_bls12_381_pairing_amd as B
 from plonky2_bls12_381_pairing_amd import _lib
 
 NAMES = {0: "product", 1: "sum", 2: "sum+sweep", 3: "two-product", 4: "copy in", 5: "copy fill", 6: "copy const",
-         7: "copy spill", 8: "copy out", 9: "sum+reduce", 10: "summed-operand product"}
+         7: "copy spill", 8: "copy out", 9: "sum+reduce", 10: "summed-operand product", 11: "n-product"}
 for spec in sys.argv[1:] or ["8:0"]:
     K, slots = (int(x) for x in spec.split(":"))
     ctx = B.Context(0, K, slots)

@@ -1,24 +1,55 @@
-"""Throughput sweep over lanes-per-pairing / LDS slots (development tool, needs a GPU)."""
-import os, sys, time
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+"""One-at-a-time sweep of the scheduler's knobs on the GPU (tuning aid): each setting runs in its own process,
+65,536 pairings, and reports the best Miller-loop and final-exponentiation kernel times.
+usage: gpu_sweep.py [ROUNDS]"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+KNOBS = {
+    "BLS381_ABSORB_TERMS": [0, 1, 2],
+    "BLS381_ABSORB_USES2": [2, 8, 100],
+    "BLS381_ABSORB_USES3": [0, 1, 4, 100],
+    "BLS381_VB_EAGER": [100, 200, 800, 100000],
+    "BLS381_DB_EAGER": [2, 4, 100],
+    "BLS381_WINDOW": [200, 400, 1000, 2000],
+    "BLS381_GROUP_WIDE": [0],
+    "BLS381_LIN_BIAS": [0],
+    "BLS381_SPLIT_MUL": [1],
+}
+variants = [("default", {})]
+for k, vals in KNOBS.items():
+    for v in vals:
+        variants.append(("%s=%s" % (k[7:], v), {k: str(v)}))
+child = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
 import numpy as np
 from helpers import *
 import plonky2_bls12_381_pairing_amd as B
 ps, qs = random_pairs(6, 3)
-n = int(os.environ.get("SWEEP_N", "65536"))
+n = 65536
 g1 = np.tile(g1_array(ps), (n // 6 + 1, 1))[:n]; g2 = np.tile(g2_array(qs), (n // 6 + 1, 1))[:n]
-want = [R.native_pairing([ps[i]], [qs[i]]) for i in range(6)]
-for spec in sys.argv[1:]:
-    K, slots = [int(x) for x in spec.split(':')]
-    try:
-        ctx = B.Context(0, K, slots)
-    except Exception as e:
-        print(spec, "ctx failed:", e, flush=True); continue
-    best = None
-    for rep in range(3):
-        out = ctx.pairing_batch(g1, g2); ms = ctx.last_timing()
-        if best is None or ms[3] < best[3]: best = ms
-    ok = all(fq12_from_row(out[i]) == want[i] for i in range(6)) and fq12_from_row(out[n - 1]) == want[(n - 1) % 6]
-    print("K=%2d slots=%3d ok=%s miller %.2f fe1+inv %.2f fe2 %.2f total %.2f ms -> %.0f pairings/s" % (K, slots, ok, best[0], best[1], best[2], best[3], n / (best[3] * 1e-3)), flush=True)
-    ctx.close()
+ctx = B.Context(0)
+best = [1e9, 1e9]
+for rep in range(4):
+    ctx.pairing_batch(g1, g2); ms = ctx.last_timing()
+    if rep: best = [min(best[0], ms[0]), min(best[1], ms[2])]
+print("T", best[0], best[1], flush=True)
+''' % (ROOT, ROOT)
+res = {}
+for r in range(rounds):
+    for name, venv in variants:
+        env = dict(os.environ, BLS381_SLICE="65536", **venv)
+        try:
+            out = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=120)
+        except subprocess.TimeoutExpired:
+            print(name, "timeout", flush=True); continue
+        got = [l for l in out.stdout.splitlines() if l.startswith("T ")]
+        if not got:
+            print(name, "failed:", out.stderr.strip().splitlines()[-1:] , flush=True); continue
+        _, m, f = got[0].split()
+        a = res.setdefault(name, [1e9, 1e9])
+        a[0] = min(a[0], float(m)); a[1] = min(a[1], float(f))
+        print("%-28s miller %.3f fe2 %.3f" % (name, float(m), float(f)), flush=True)
+print("---- best of %d" % rounds)
+for name, (m, f) in res.items():
+    print("%-28s miller %.3f (%+.1f%%) fe2 %.3f (%+.1f%%)" % (name, m, 100 * (m / res["default"][0] - 1), f, 100 * (f / res["default"][1] - 1)))
