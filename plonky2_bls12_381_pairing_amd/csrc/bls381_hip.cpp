@@ -50,7 +50,9 @@ static void fill_vm_constants(std::vector<uint32_t>& c) {
     std::memcpy(c.data(), BLS381_VMCONST28, sizeof(BLS381_VMCONST28));
 }
 // ------------------------------------------------------------------ programs
-static Dag build_named(const std::string& which) {
+// (K: the lane-group width the program will be scheduled for; it decides the form of the Fq6 products)
+static Dag build_named(const std::string& which, int K) {
+    set_lazy_products_for(K);
     if (which == "miller") return build_miller();
     if (which == "g2prep") return build_g2_prepare();
     if (which == "millerfq") return build_miller_fixed_q();
@@ -196,7 +198,7 @@ static Program microbench_program(const std::string& which, int K, int slots) {
     if (h.type == ST_LIN) h.max_terms |= (uint32_t)nterms;
     if (h.type == ST_FMUL || h.type == ST_DOT2) h.max_terms = (uint32_t)width;
     if (h.type == ST_DOTN) {
-        if (width < 3 || width > DOTN_MAX_PAIRS) throw std::runtime_error("bad microbenchmark " + which);
+        if (width < 3 || width > DOTN_MAX_PAIRS || K != 6) throw std::runtime_error("bad microbenchmark " + which);
         h.max_terms = (uint32_t)width;
     }
     for (int s = 0; s < 1000; s++) {
@@ -240,7 +242,7 @@ static int upload_program(bls381_ctx* c, const std::string& which) {
         int K, slots;
         program_geometry(c, which, K, slots);
         if (which.rfind("t_", 0) == 0) dp.host = microbench_program(which, K, slots);
-        else dp.host = schedule(build_named(base_name(which)), K, slots, which);
+        else dp.host = schedule(build_named(base_name(which), K), K, slots, which);
     } catch (std::exception& e) {
         return fail(BLS381_ERR_INVALID, std::string("program ") + which + ": " + e.what());
     }
@@ -1427,7 +1429,7 @@ extern "C" int bls381_debug_program(const char* which, int K, int lds_slots, uin
     if (lds_slots == 0) lds_slots = default_slots(K);
     Program p;
     try {
-        p = schedule(build_named(which), K, lds_slots, which);
+        p = schedule(build_named(which, K), K, lds_slots, which);
     } catch (std::exception& e) {
         return fail(BLS381_ERR_INVALID, e.what());
     }

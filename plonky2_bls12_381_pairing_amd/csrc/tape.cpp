@@ -771,7 +771,10 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         // a step holding a two-product op runs the two-product multiplier on every lane; single
         // products in it use zero for the second product
         h.type = st.cls == OC_FMUL ? (any_dot2 ? ST_DOT2 : ST_FMUL) : (st.cls == OC_LIN ? ST_LIN : (st.cls == OC_DOTN ? ST_DOTN : ST_COPY));
-        if (st.cls == OC_DOTN) h.max_terms = 3;  // the kernel multiplies at least three products
+        if (st.cls == OC_DOTN) {
+            if (K != 6) throw std::runtime_error("scheduler: n-product operations need 6 lanes per group (" + name + ")");
+            h.max_terms = 3;  // the kernel multiplies at least three products
+        }
         if (st.cls == OC_FMUL) h.max_terms = (uint32_t)mul_width;
         for (int r = 0; r < K; r++) {
             OpDesc d; std::memset(&d, 0, sizeof d);

@@ -77,6 +77,10 @@ struct Program {
 // Schedules `dag` for groups of K lanes with at most `lds_slots` LDS slots per group.
 Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name);
 
+// Chooses the form of the Fq6 products for the programs this thread builds next: n-product operations for K = 6
+// when BLS381_LAZY_PRODUCTS=1, Karatsuba over two-product operations otherwise (tower_sym.cpp).
+void set_lazy_products_for(int K);
+
 // ---- program builders (symbolic versions of the reference's native functions) ----
 // gin/gout slot numbering: G1 = {x, y}; G2 = {x.c0, x.c1, y.c0, y.c1};
 // Fq12 = ark tower order c0.c0.c0, c0.c0.c1, c0.c1.c0, ... c1.c2.c1.

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             if (flags & 2u) reduce28(r);  // sweeps as well
             else if (flags) normalise28(r);
             lds_store(dst, r);
-        } else if (type == ST_DOTN) {
+        } else if (K == 6 && type == ST_DOTN) {  // (compiled into the 6-lane interpreter only)
             // dst = (sum over t of a_t * (+-b_t)) / 2^392 with one reduction.  Operand scanning: every product of
             // two digits goes to its column's 64-bit accumulator; the operands of product t + 1 are loaded while
             // product t is multiplied.  Ops with fewer products than the step's largest count are padded with

@@ -375,23 +375,49 @@ __device__ __forceinline__ void w_load(const u32* base, u32 ref, const u32* T, c
     x[8] = c.x; x[9] = c.y; x[10] = c.z; x[11] = c.w;
 }
 
-// lpp lanes per proof: a workgroup of blockDim.x lanes serves blockDim.x / lpp proofs side by side
+// lpp lanes per proof: a workgroup of blockDim.x lanes serves blockDim.x / lpp proofs side by side.
+// Nine operand reads in ten name a row written at most 256 rows earlier, six in ten one at most 64 rows earlier,
+// but with thousands of proofs in flight those rows have left every cache by then.  So each proof keeps its last
+// rows in LDS as well: `cache_rows` entries (a power of two, 0 = none) of 12 words, direct-mapped by row number,
+// beside a tag array holding row + 1.  A read whose tag matches comes from LDS, any other from the trace in global
+// memory, which always holds every finished row.  The lanes of a proof sit in one wave (lpp divides 64) and a wave
+// executes its LDS instructions in order, all lanes together: every lane's reads of an iteration precede every
+// lane's writes of it, so an entry is never seen half replaced.
 __global__ __launch_bounds__(256) void witness_kernel(const WitnessOp* ops, const u32* level_start, int nlevels,
                                                       u32* trace, size_t rows, const u32* consts, const u32* inputs,
-                                                      int lpp, int nproofs) {
+                                                      int lpp, int nproofs, int cache_rows) {
+    extern __shared__ uint4 wcache[];
     const int proof = blockIdx.x * (blockDim.x / lpp) + threadIdx.x / lpp;
     const int sub = threadIdx.x % lpp;
     const bool live = proof < nproofs;
     u32* T = trace + (size_t)(live ? proof : 0) * rows * 12;
     const u32* in = inputs + (size_t)(live ? proof : 0) * 6 * 12;
     const u32 P[12] = BLS381_P_LIMBS;
+    // this proof's part of the cache: cache_rows x 3 uint4 of data, then (after all proofs' data) the tags
+    const int per_block = blockDim.x / lpp, pl = threadIdx.x / lpp;
+    uint4* cdata = wcache + (size_t)pl * cache_rows * 3;
+    u32* ctag = reinterpret_cast<u32*>(wcache + (size_t)per_block * cache_rows * 3) + (size_t)pl * cache_rows;
+    const u32 cmask = (u32)cache_rows - 1u;
+    for (int i = sub; i < cache_rows; i += lpp) ctag[i] = 0;
+    __syncthreads();
+    auto load = [&](u32 ref, u32* x) {
+        const u32 sp = ref >> 30, idx = ref & WREF_MASK;
+        if (cache_rows && sp == 0 && ctag[idx & cmask] == idx + 1u) {
+            const uint4* q = cdata + (size_t)(idx & cmask) * 3;
+            uint4 a = q[0], b = q[1], c = q[2];
+            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+            x[8] = c.x; x[9] = c.y; x[10] = c.z; x[11] = c.w;
+        } else {
+            w_load(T, ref, T, consts, in, x);
+        }
+    };
     for (int l = 0; l < nlevels; l++) {
         const u32 lo = level_start[l], hi = level_start[l + 1];
         for (u32 i = lo + sub; live && i < hi; i += lpp) {
             const WitnessOp op = ops[i];
             const u32 kind = op.dst >> 28, row = op.dst & 0x0fffffffu;
             u32 a[12], b[12], r[12];
-            w_load(T, op.a, T, consts, in, a);
+            load(op.a, a);
             if (kind == WK_INV) {
                 // the only inv_nonnative on the path inverts the constant 2 (curves/g2.rs:149-151)
                 const uint4* q = reinterpret_cast<const uint4*>(consts + (size_t)WC_TWO_INV * 12);
@@ -399,17 +425,17 @@ __global__ __launch_bounds__(256) void witness_kernel(const WitnessOp* ops, cons
                 r[0] = v0.x; r[1] = v0.y; r[2] = v0.z; r[3] = v0.w; r[4] = v1.x; r[5] = v1.y; r[6] = v1.z; r[7] = v1.w;
                 r[8] = v2.x; r[9] = v2.y; r[10] = v2.z; r[11] = v2.w;
             } else if (kind == WK_MUL) {
-                w_load(T, op.b, T, consts, in, b);
+                load(op.b, b);
                 fp_mul_canon(a, b, r);  // rows are canonical values: no Montgomery factor to carry
             } else if (kind == WK_ADD) {
-                w_load(T, op.b, T, consts, in, b);
+                load(op.b, b);
                 carry_t c;
                 r[0] = add_co(a[0], b[0], c);
 #pragma unroll
                 for (int k = 1; k < 12; k++) r[k] = addc_co(a[k], b[k], c);
                 fp_cond_sub_p(r);
             } else if (kind == WK_SUB) {
-                w_load(T, op.b, T, consts, in, b);
+                load(op.b, b);
                 carry_t c;
                 r[0] = sub_co(a[0], b[0], c);
 #pragma unroll
@@ -433,6 +459,19 @@ __global__ __launch_bounds__(256) void witness_kernel(const WitnessOp* ops, cons
             d[0] = make_uint4(r[0], r[1], r[2], r[3]);
             d[1] = make_uint4(r[4], r[5], r[6], r[7]);
             d[2] = make_uint4(r[8], r[9], r[10], r[11]);
+            if (cache_rows) {
+                // (the compiler must not move these stores above the reads of this iteration, nor the next
+                // iteration's reads above them: other lanes of the wave read what this lane replaces)
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                uint4* q = cdata + (size_t)(row & cmask) * 3;
+                q[0] = make_uint4(r[0], r[1], r[2], r[3]);
+                q[1] = make_uint4(r[4], r[5], r[6], r[7]);
+                q[2] = make_uint4(r[8], r[9], r[10], r[11]);
+                ctag[row & cmask] = row + 1u;
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         __syncthreads();
     }
@@ -611,8 +650,13 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
     }
     if (const char* e = getenv("BLS381_WIT_BLOCK")) block = atoi(e);
     if (const char* e = getenv("BLS381_WIT_LPP")) lpp = atoi(e);
-    if (block < 1 || block > 1024 || block % 64) { err = "BLS381_WIT_BLOCK must be a multiple of 64 up to 1024"; return -1; }
-    if (lpp < 1 || lpp > block || block % lpp) { err = "BLS381_WIT_LPP must divide BLS381_WIT_BLOCK"; return -1; }
+    int cache_rows = 32;  // rows per proof kept in LDS, see witness_kernel (measured, proofs/s at 16 lanes per proof: none 191 k, 16 rows 196 k, 32 rows 203 k, 64 rows 153 k: larger caches cost occupancy)
+    if (const char* e = getenv("BLS381_WIT_CACHE")) cache_rows = atoi(e);
+    if (block < 1 || block > 256 || block % 64) { err = "BLS381_WIT_BLOCK must be 64, 128, 192 or 256"; return -1; }
+    if (lpp < 1 || lpp > 64 || 64 % lpp) { err = "BLS381_WIT_LPP must divide 64"; return -1; }
+    if (cache_rows < 0 || cache_rows > 1024 || (cache_rows & (cache_rows - 1))) { err = "BLS381_WIT_CACHE must be 0 or a power of two up to 1024"; return -1; }
+    const size_t cache_bytes = (size_t)(block / lpp) * cache_rows * 52;
+    if (cache_bytes > 64 * 1024) { err = "BLS381_WIT_CACHE: more than 64 KiB of LDS per workgroup"; return -1; }
     const int per_block = block / lpp;
     for (size_t off = 0; off < n; off += CH) {
         int m = (int)std::min(CH, n - off);
@@ -629,8 +673,8 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         WCHK(hipMemcpyAsync(d_g2, g2 + off * 24, (size_t)m * 192, in_kind, stream));
         hipLaunchKernelGGL(witness_inputs_kernel, dim3((m * 6 + 63) / 64), dim3(64), 0, stream, d_g1, d_g2, (u32*)d_inputs_, m);
         WCHK(hipGetLastError());
-        hipLaunchKernelGGL(witness_kernel, dim3((m + per_block - 1) / per_block), dim3(block), 0, stream, d_ops_[0], d_levels_[0],
-                           (int)P.level_start[0].size() - 1, d_trace_m, P.n_rows, d_consts_, (const u32*)d_inputs_, lpp, m);
+        hipLaunchKernelGGL(witness_kernel, dim3((m + per_block - 1) / per_block), dim3(block), cache_bytes, stream, d_ops_[0], d_levels_[0],
+                           (int)P.level_start[0].size() - 1, d_trace_m, P.n_rows, d_consts_, (const u32*)d_inputs_, lpp, m, cache_rows);
         WCHK(hipGetLastError());
         u32* d_x = (u32*)d_x_;
         u32* d_inv = d_x + (size_t)m * 144;
@@ -642,8 +686,8 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         hipLaunchKernelGGL(witness_scatter_kernel, dim3((m * 12 + 63) / 64), dim3(64), 0, stream, d_trace_m, P.n_rows,
                            P.gen_start, d_inv, m);
         WCHK(hipGetLastError());
-        hipLaunchKernelGGL(witness_kernel, dim3((m + per_block - 1) / per_block), dim3(block), 0, stream, d_ops_[1], d_levels_[1],
-                           (int)P.level_start[1].size() - 1, d_trace_m, P.n_rows, d_consts_, (const u32*)d_inputs_, lpp, m);
+        hipLaunchKernelGGL(witness_kernel, dim3((m + per_block - 1) / per_block), dim3(block), cache_bytes, stream, d_ops_[1], d_levels_[1],
+                           (int)P.level_start[1].size() - 1, d_trace_m, P.n_rows, d_consts_, (const u32*)d_inputs_, lpp, m, cache_rows);
         WCHK(hipGetLastError());
         if (aux && (aux->mul_quot || aux->carry || aux->inv_quot)) {
             const size_t n_mul = P.counts[WK_MUL];

@@ -293,6 +293,47 @@ def test_pairing_witness_trace(ctx):
         assert R.myfq12_to_fq12(out) == R.native_pairing([ps[e]], [qs[e]])
 
 
+def test_pairing_witness_trace_256_proofs(ctx, CO, monkeypatch):
+    """The configured size of the witness workload: 256 proofs.  Every row of a strided sample of proofs against the
+    CPU replay, the pairing value inside the trace against the C oracle's native pairing for all 256, and the same
+    batch again in several passes (host form: three of at most 96 proofs, device form: six of at most 50), which must
+    give the same bytes."""
+    import torch
+    import witness_ref as W
+    from plonky2_bls12_381_pairing_amd import _lib
+    bp, bq = H.random_pairs(16, 2560)
+    ps = [bp[i % 16] for i in range(256)]
+    qs = [bq[i // 16] for i in range(256)]
+    g1, g2 = H.g1_array(ps), H.g2_array(qs)
+    trace = ctx.pairing_witness_batch(g1, g2)
+    assert trace.shape == (256, 141376, 12)
+    out_rows = None
+    for e in range(0, 256, 17):
+        tr, out = W.pairing_witness(ps[e], qs[e])
+        want = np.array([R.fq_to_u32_limbs(v) for _, v in tr.rows], dtype=np.uint32)
+        bad = np.nonzero((trace[e] != want).any(axis=1))[0]
+        assert bad.size == 0, (e, bad[:5], [tr.rows[i][0] for i in bad[:5]])
+        # where the pairing value's twelve coefficients (MyFq12 order) sit: the same rows in every proof
+        vals = [v for _, v in tr.rows]
+        rows = [max(i for i in range(141300, 141376) if vals[i] == o) for o in out]
+        assert out_rows is None or rows == out_rows
+        out_rows = rows
+    native = CO.pairing_batch(g1, g2)
+    for e in range(256):
+        coeffs = R.myfq12_from_fq12(H.fq12_from_row(native[e]))
+        assert np.array_equal(trace[e][out_rows], np.array([R.fq_to_u32_limbs(v) for v in coeffs], dtype=np.uint32)), e
+    monkeypatch.setenv("BLS381_WIT_CH", "96")
+    assert np.array_equal(ctx.pairing_witness_batch(g1, g2), trace)
+    monkeypatch.setenv("BLS381_WIT_CH", "50")
+    dev = torch.device("cuda", 0)
+    d1 = torch.from_numpy(g1.view(np.int64)).to(dev)
+    d2 = torch.from_numpy(g2.view(np.int64)).to(dev)
+    d_out = torch.zeros(trace.size, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib.bls381_pairing_witness_batch_dev(ctx.handle, d1.data_ptr(), d2.data_ptr(), 256, d_out.data_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint32).reshape(trace.shape), trace)
+
+
 def test_pairing_witness_auxiliary_values(ctx):
     """The gadgets' auxiliary values beside the trace (mul quotients, add/sub/neg carry bytes, the inv row's quotient)
     against the CPU replay, which forms them from Python integers: a * b == q * p + r for every one of the 70,656
@@ -472,7 +513,7 @@ def test_other_lane_group_geometries(lanes, slots):
         prep.close()
 
 
-@pytest.mark.parametrize("lanes", [6, 8])
+@pytest.mark.parametrize("lanes", [6])
 def test_lazy_product_programs(lanes, monkeypatch):
     """The programs built from n-product operations (BLS381_LAZY_PRODUCTS=1: schoolbook Fq6 products and line products,
     one reduction per component) give the same pairings, Miller values and Fq12 products, bit for bit."""

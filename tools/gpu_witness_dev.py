@@ -21,7 +21,7 @@ for rep in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     check(lib.bls381_pairing_witness_batch_dev(ctx.handle, g1.data_ptr(), g2.data_ptr(), n, trace.data_ptr()))
     dt = time.perf_counter() - t0
-print("block %s chunk %s: %d proofs %.1f ms = %.4f ms per proof, %.0f proofs/s, %.0f GB/s written" %
-      (os.environ.get("BLS381_WIT_BLOCK", "default"), os.environ.get("BLS381_WIT_CH", "default"), n, dt * 1e3, dt * 1e3 / n, n / dt,
+print("cache %s block %s chunk %s: %d proofs %.1f ms = %.4f ms per proof, %.0f proofs/s, %.0f GB/s written" %
+      (os.environ.get("BLS381_WIT_CACHE", "default"), os.environ.get("BLS381_WIT_BLOCK", "default"), os.environ.get("BLS381_WIT_CH", "default"), n, dt * 1e3, dt * 1e3 / n, n / dt,
        n * rows * 48 / dt / 1e9), flush=True)
 print("checksum", int(trace[:8].to(torch.int64).sum().item()), int(trace[-8:].to(torch.int64).sum().item()))
