@@ -118,6 +118,14 @@ def main():
     if not np.array_equal(out[sample], ref):
         raise SystemExit("rank %d: GPU pairings differ from the CPU oracle" % rank)
 
+    # which ranks took part: every rank contributes its number through the process group
+    ranks_seen = [0]
+    if dist is not None:
+        mine = torch.tensor([rank], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        ranks_seen = sorted(int(t.item()) for t in got)
+
     if rank == 0:
         value = world * BATCH * args.steps / elapsed
         ms_fe2 = float(np.mean([k[2] for k in kern_ms]))
@@ -125,6 +133,8 @@ def main():
         ms_fe1 = float(np.mean([k[1] for k in kern_ms]))
         achieved = BATCH * W_FE2 / (ms_fe2 * 1e-3)
         peak_measured = ctx.calibrate_mac_rate()
+        # the clock the calibration loop ran at: its rate over one multiply-accumulate per lane per 4 cycles
+        calib_clock_ghz = peak_measured / (256 * 4 * 64 / 4) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
@@ -137,6 +147,8 @@ def main():
             "value": value,
             "unit": "pairings/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
+            "backend": backend if dist is not None else None,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -157,14 +169,22 @@ def main():
                 "unit": "TMAC/s (32x32->64 multiply-accumulates)",
                 "frac": achieved / PEAK_MAC,
                 "traffic": traffic,
+                "traffic_source": "profiles/roofline_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                  "command recorded earlier (tools/gpu_round_profile.sh), not measured in this run",
                 "peak_measured": peak_measured / 1e12,
+                "peak_measured_clock_GHz": calib_clock_ghz,
                 "frac_of_measured_peak": achieved / peak_measured,
                 "whole_step_frac": value / world * W_PAIR / PEAK_MAC,
                 "kernel_ms": {"miller": ms_miller, "fe1_plus_inversion": ms_fe1, "fe2": ms_fe2},
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            cores = min(16, os.cpu_count() or 1)
+            # every core this process may use: its affinity mask, or what the box grants through OMP_NUM_THREADS
+            # (a one-GPU share of a larger host); the machine's total is stated beside it
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            granted = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+            cores = max(1, min(avail, granted) if granted > 0 else avail)
+            res["host_cores_total"] = os.cpu_count()
             CO.set_threads(cores)
             probe = np.arange(8 * cores) * 37 % BATCH
             t1 = time.perf_counter()

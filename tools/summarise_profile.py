@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_round")
-tag = sys.argv[1] if len(sys.argv) > 1 else "v5"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"   # file prefix: the round the measurement belongs to
 
 
 def newest(pattern):
@@ -61,6 +61,7 @@ for k in ("miller", "fe2"):
         res.setdefault("lds_bank_conflict_cycles_per_cu", {})[k] = mean(sq[k]["SQ_LDS_BANK_CONFLICT"]) / 256
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "profiles", "roofline_traffic.json"), "w"), indent=1)
-shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(ROOT, "profiles", "r1_bench_%s.json" % tag))
-shutil.copy(newest("stats/*/*_kernel_stats.csv"), os.path.join(ROOT, "profiles", "r1_bench_kernel_stats_%s.csv" % tag))
+json.dump(res, open(os.path.join(ROOT, "profiles", "%s_roofline_traffic.json" % tag), "w"), indent=1)
+shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(ROOT, "profiles", "%s_bench.json" % tag))
+shutil.copy(newest("stats/*/*_kernel_stats.csv"), os.path.join(ROOT, "profiles", "%s_bench_kernel_stats.csv" % tag))
 print(json.dumps(res, indent=1))
