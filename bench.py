@@ -72,7 +72,9 @@ def main():
     backend = os.environ.get("BLS381_BENCH_BACKEND", "nccl")
     device_index = int(os.environ.get("BLS381_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(device_index)
-    if world > 1:
+    # BLS381_BENCH_FORCE_DIST=1 builds the process group even for one rank: on a one-GPU box that runs the RCCL
+    # code path (initialisation, barrier, device-tensor all-reduce and all-gather) the multi-GPU launch will take
+    if world > 1 or os.environ.get("BLS381_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))

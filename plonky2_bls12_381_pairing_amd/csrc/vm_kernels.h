@@ -233,14 +233,21 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                 }
             };
 #define BLS381_IC(n) std::integral_constant<int, n>()
-            switch (max_terms) {  // uniform
-                case 1: terms(BLS381_IC(0), BLS381_IC(1)); break;
-                case 2: terms(BLS381_IC(0), BLS381_IC(2)); break;
-                case 3: terms(BLS381_IC(0), BLS381_IC(3)); break;
-                case 4: terms(BLS381_IC(0), BLS381_IC(4)); break;
-                case 5: terms(BLS381_IC(0), BLS381_IC(4)); terms(BLS381_IC(4), BLS381_IC(1)); break;
-                case 6: terms(BLS381_IC(0), BLS381_IC(4)); terms(BLS381_IC(4), BLS381_IC(2)); break;
-                default: terms(BLS381_IC(0), BLS381_IC(4)); terms(BLS381_IC(4), BLS381_IC(3)); break;
+            // (uniform; written as nested two-way branches: a switch comes out of the compiler as a chain of
+            // scalar flag updates)
+            if (max_terms <= 4) {
+                if (max_terms <= 2) {
+                    if (max_terms <= 1) terms(BLS381_IC(0), BLS381_IC(1));
+                    else terms(BLS381_IC(0), BLS381_IC(2));
+                } else {
+                    if (max_terms == 3) terms(BLS381_IC(0), BLS381_IC(3));
+                    else terms(BLS381_IC(0), BLS381_IC(4));
+                }
+            } else {
+                terms(BLS381_IC(0), BLS381_IC(4));
+                if (max_terms == 5) terms(BLS381_IC(4), BLS381_IC(1));
+                else if (max_terms == 6) terms(BLS381_IC(4), BLS381_IC(2));
+                else terms(BLS381_IC(4), BLS381_IC(3));
             }
 #undef BLS381_IC
             u32 r[D28];
@@ -303,25 +310,26 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
         } else if (type == ST_DOT2 || type == ST_FMUL) {
             // operands: a, b (, c, d), each a signed sum of up to max_terms slots added up as they are loaded
             auto BYTE = [&](u32 word, int jop) -> u32 { return (word >> (jop * 8)) & 0xffu; };
-            auto operand = [&](int jop, u32* v) {
+            auto operand2 = [&](int jop, u32* v) {
                 const u32 e0 = BYTE(dy, jop), e1 = BYTE(dz, jop);
                 const u32 m0 = (u32)((int)(e0 << 24) >> 31), m1 = (u32)((int)(e1 << 24) >> 31);
                 u32 x0[D28], x1[D28];
                 lds_load(e0 & 0x7fu, x0);
                 lds_load(e1 & 0x7fu, x1);
-                if (max_terms == 2) {
-                    // (x ^ m) is one short of -x for a negated term: the first term starts from their count
-                    xor_add28_first(v, x0, m0, 0u - (m0 + m1));
-                    xor_add28(v, x1, m1);
-                } else {
-                    const u32 e2 = BYTE(d3, jop);
-                    const u32 m2 = (u32)((int)(e2 << 24) >> 31);
-                    u32 x2[D28];
-                    lds_load(e2 & 0x7fu, x2);
-                    xor_add28_first(v, x0, m0, 0u - (m0 + m1 + m2));
-                    xor_add28(v, x1, m1);
-                    xor_add28(v, x2, m2);
-                }
+                // (x ^ m) is one short of -x for a negated term: the first term starts from their count
+                xor_add28_first(v, x0, m0, 0u - (m0 + m1));
+                xor_add28(v, x1, m1);
+            };
+            auto operand3 = [&](int jop, u32* v) {
+                const u32 e0 = BYTE(dy, jop), e1 = BYTE(dz, jop), e2 = BYTE(d3, jop);
+                const u32 m0 = (u32)((int)(e0 << 24) >> 31), m1 = (u32)((int)(e1 << 24) >> 31), m2 = (u32)((int)(e2 << 24) >> 31);
+                u32 x0[D28], x1[D28], x2[D28];
+                lds_load(e0 & 0x7fu, x0);
+                lds_load(e1 & 0x7fu, x1);
+                lds_load(e2 & 0x7fu, x2);
+                xor_add28_first(v, x0, m0, 0u - (m0 + m1 + m2));
+                xor_add28(v, x1, m1);
+                xor_add28(v, x2, m2);
             };
             u32 a[D28], b[D28], r[D28];
             if (type == ST_DOT2) {
@@ -337,20 +345,20 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                     xor_add28_first(nd, d, m, m & 1u);
 #pragma unroll
                     for (int i = 0; i < D28; i++) d[i] = nd[i];
+                } else if (max_terms == 2) {
+                    operand2(0, a); operand2(1, b); operand2(2, c); operand2(3, d);
                 } else {
-                    operand(0, a);
-                    operand(1, b);
-                    operand(2, c);
-                    operand(3, d);
+                    operand3(0, a); operand3(1, b); operand3(2, c); operand3(3, d);
                 }
                 fp28_dot2(a, b, c, d, r);
             } else {
                 if (max_terms <= 1) {
                     lds_load(BYTE(dy, 0) & 0x7fu, a);
                     lds_load(BYTE(dy, 1) & 0x7fu, b);
+                } else if (max_terms == 2) {
+                    operand2(0, a); operand2(1, b);
                 } else {
-                    operand(0, a);
-                    operand(1, b);
+                    operand3(0, a); operand3(1, b);
                 }
                 fp28_mul(a, b, r);
             }
