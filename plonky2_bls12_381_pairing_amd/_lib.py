@@ -5,7 +5,9 @@ There is no CPU implementation behind these bindings: without the shared library
 and without a gfx950 device every compute call returns an error.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BLS381_LIB_PATH") or os.path.join(_HERE, "libbls381_hip.so")  # (the override: A/B builds)
@@ -14,6 +16,20 @@ if not os.path.exists(LIB_PATH):
     raise ImportError(
         "libbls381_hip.so is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+
+# One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so under the soname of the system's
+# (/opt/rocm), and the dynamic loader hands whichever was loaded first to every later user of that soname.  Torch on
+# the system's copy can fail to find its GPUs, so where torch is installed its copy is loaded first, whether or not
+# torch itself has been imported yet: this library and a later `import torch` then share it in either order.
+if "torch" not in sys.modules and os.environ.get("BLS381_NO_TORCH_RUNTIME") != "1":
+    try:
+        _spec = importlib.util.find_spec("torch")
+        _dirs = list(_spec.submodule_search_locations) if _spec and _spec.submodule_search_locations else []
+        _hip = os.path.join(_dirs[0], "lib", "libamdhip64.so") if _dirs else ""
+        if _hip and os.path.exists(_hip):
+            C.CDLL(_hip, mode=C.RTLD_GLOBAL)
+    except (ImportError, OSError, ValueError):
+        pass  # no torch, or its runtime does not load here: the system's runtime serves this library alone
 
 lib = C.CDLL(LIB_PATH)
 

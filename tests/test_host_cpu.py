@@ -4,6 +4,7 @@ product path fails loudly when no GPU is present."""
 import ctypes as C
 import os
 import re
+import sys
 
 import pytest
 
@@ -202,3 +203,15 @@ def test_witness_program_rows_match_circuit_op_totals():
     tr, _ = W.pairing_witness(R.G1_GEN, R.G2_GEN)
     names = ["add", "sub", "mul", "neg", "inv", "gen"]
     assert all(names[kinds[i]] == tr.rows[i][0] for i in range(len(kinds)))
+
+
+def test_one_hip_runtime_in_either_import_order():
+    """This package imported before torch, and torch after it, end up on one libamdhip64 (torch's copy, loaded
+    first by the package's loader): two runtimes in one process are what makes torch lose its GPUs."""
+    import subprocess
+    code = ("import plonky2_bls12_381_pairing_amd, torch\n"
+            "print(sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l)))")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr[-500:]
+    libs = eval(out.stdout.strip().splitlines()[-1])
+    assert len(libs) == 1 and "torch" in libs[0], libs
