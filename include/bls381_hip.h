@@ -200,6 +200,13 @@ int bls381_multi_ctx_pairing_witness_batch(bls381_multi_ctx*, const uint64_t* g1
 int bls381_multi_ctx_verify_batch(bls381_multi_ctx*, const uint8_t* pk48, const uint8_t* msg96, const uint8_t* sig96, size_t n,
                                   int check_subgroup_mask, uint8_t* verdict, uint8_t* status);
 
+/* The context's workspace grows on demand (a call larger than any before it frees and reallocates device buffers
+ * inside the call).  bls381_ctx_reserve does that growing ahead of time for pairing, Miller-loop and
+ * final-exponentiation calls of up to max_items items (one pair or one Fq12 each; batches are cut into chunks of
+ * 65,536, so larger values reserve the same), and builds the program variants small batches use: the first large call
+ * then costs what every later one does.  No counterpart in the reference (host memory there is the allocator's). */
+int bls381_ctx_reserve(bls381_ctx*, size_t max_items);
+
 /* bls381_pairing_batch_dev for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same kernels and results as
  * bls381_pairing_batch_dev, but the workspace (slot arrays, carry and spill arrays) is a fixed 32 MiB array that

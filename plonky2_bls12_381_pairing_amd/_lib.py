@@ -49,6 +49,7 @@ def _sig(name, restype, *argtypes):
 _sig("bls381_ctx_create", C.c_int, C.POINTER(ctxp), C.c_int)
 _sig("bls381_ctx_create_ex", C.c_int, C.POINTER(ctxp), C.c_int, C.c_int, C.c_int)
 _sig("bls381_ctx_destroy", None, ctxp)
+_sig("bls381_ctx_reserve", C.c_int, ctxp, C.c_size_t)
 _sig("bls381_last_error", C.c_char_p)
 _sig("bls381_miller_loop_batch", C.c_int, ctxp, u64p, u64p, u8p, C.c_size_t, u64p)
 _sig("bls381_final_exp_batch", C.c_int, ctxp, u64p, C.c_size_t, u64p, u8p)
@@ -117,7 +118,7 @@ _sig("bls381_calibrate_mac_rate", C.c_int, ctxp, C.POINTER(C.c_double))
 
 # every symbol include/bls381_hip.h declares
 EXPORTED = [
-    "bls381_ctx_create", "bls381_ctx_create_ex", "bls381_ctx_destroy", "bls381_last_error",
+    "bls381_ctx_create", "bls381_ctx_create_ex", "bls381_ctx_destroy", "bls381_ctx_reserve", "bls381_last_error",
     "bls381_miller_loop_batch", "bls381_final_exp_batch", "bls381_pairing_batch", "bls381_multi_miller_loop",
     "bls381_multi_pairing", "bls381_finish_multi_pairing", "bls381_g2_prepare_batch", "bls381_ell_batch",
     "bls381_easy_part_batch", "bls381_hard_part_batch", "bls381_frobenius_batch", "bls381_conjugate_batch", "bls381_pow_batch", "bls381_pow_x_batch", "bls381_fq12_mul_batch",

@@ -570,6 +570,27 @@ extern "C" int bls381_miller_loop_batch_dev(bls381_ctx* c, const uint64_t* g1, c
     return miller_dev_locked(c, g1, g2, flags, n, out, false);
 }
 
+// Grows the context's workspace now to what pairing / Miller-loop / final-exponentiation calls of up to max_items
+// items need (batches are processed in chunks of CHUNK items, so more than that changes nothing), and uploads the
+// 16-lane program variants that small batches use: later calls within the limit then make no allocation.
+extern "C" int bls381_ctx_reserve(bls381_ctx* c, size_t max_items) {
+    CTX_GUARD(c);
+    if (max_items == 0) return 0;
+    const int npad = pad_elems(std::min<size_t>(max_items, CHUNK));
+    HIPCHK(c->bufA.ensure(soa_bytes(12, npad)));  // (two-pair items bring 12 input slots, single pairs 6)
+    HIPCHK(c->bufB.ensure(soa_bytes(12, npad)));
+    HIPCHK(c->bufC.ensure(soa_bytes(FE_CARRY, npad)));
+    size_t tmp = 0;
+    std::vector<std::string> names = {"miller", "fe1", "fe2"};
+    if (c->auto_geometry) for (const char* nm : {"miller@16", "fe1@16", "fe2@16"}) names.push_back(nm);
+    for (const std::string& nm : names) {
+        if (!c->progs.count(nm)) { int rc = upload_program(c, nm); if (rc) return rc; }
+        tmp = std::max(tmp, spill_bytes(c->progs[nm], npad));
+    }
+    HIPCHK(c->bufTmp.ensure(tmp));
+    return 0;
+}
+
 // bls381_pairing_batch_dev for callers that cannot allocate (code under graph capture, serving loops): the same
 // kernels, their workspace carved out of this device's copy of `scratch` instead of the context's growing buffers.
 // Calls nothing that allocates; at most NOALLOC_MAX_PAIRS pairs; always the context's own lane-group width (the

@@ -80,6 +80,10 @@ class Context:
             lib.bls381_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
+    def reserve(self, max_items):
+        """Grows the workspace now for calls of up to max_items items (bls381_ctx_reserve)."""
+        check(lib.bls381_ctx_reserve(self._h, int(max_items)))
+
     def __enter__(self):
         return self
 

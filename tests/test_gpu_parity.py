@@ -969,6 +969,35 @@ def test_multi_device_context(ctx, CO):
         B.MultiContext([0, 99])
 
 
+def test_workspace_reservation(CO):
+    """bls381_ctx_reserve grows the workspace ahead of time: the first large call after it allocates nothing (the
+    device's free memory is the same before and after the call) and gives the usual values."""
+    import torch
+    import plonky2_bls12_381_pairing_amd as B
+    from plonky2_bls12_381_pairing_amd import _lib
+    ps, qs = H.random_pairs(6, 4321)
+    n = 20000
+    g1 = np.tile(H.g1_array(ps), (n // 6 + 1, 1))[:n]
+    g2 = np.tile(H.g2_array(qs), (n // 6 + 1, 1))[:n]
+    dev = torch.device("cuda", 0)
+    d1 = torch.from_numpy(g1.view(np.int64)).to(dev)
+    d2 = torch.from_numpy(g2.view(np.int64)).to(dev)
+    out = torch.empty((n, 72), dtype=torch.int64, device=dev)
+    small = torch.empty((100, 72), dtype=torch.int64, device=dev)
+    with B.Context(0) as c:
+        c.reserve(n)
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info(0)[0]
+        _lib.check(_lib.lib.bls381_pairing_batch_dev(c.handle, d1.data_ptr(), d2.data_ptr(), None, n, out.data_ptr()))
+        _lib.check(_lib.lib.bls381_pairing_batch_dev(c.handle, d1.data_ptr(), d2.data_ptr(), None, 100, small.data_ptr()))
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info(0)[0] == free_before
+        c.reserve(0)
+    got = out.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got[:6], CO.pairing_batch(g1[:6], g2[:6]))
+    assert np.array_equal(got[6:12], got[:6]) and np.array_equal(small.cpu().numpy().view(np.uint64), got[:100])
+
+
 def test_argument_errors_on_a_live_context(ctx):
     """NULL buffers, sizes past the documented limits and bad selectors: BLS381_ERR_INVALID, nothing launched,
     and the context keeps working afterwards."""
