@@ -78,7 +78,7 @@ struct Program {
 Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name);
 
 // Chooses the form of the Fq6 products for the programs this thread builds next: n-product operations for K = 6
-// when BLS381_LAZY_PRODUCTS=1, Karatsuba over two-product operations otherwise (tower_sym.cpp).
+// (unless BLS381_LAZY_PRODUCTS=0), Karatsuba over two-product operations otherwise (tower_sym.cpp).
 void set_lazy_products_for(int K);
 
 // ---- program builders (symbolic versions of the reference's native functions) ----

@@ -11,18 +11,19 @@
 
 namespace bls381 {
 
-// BLS381_LAZY_PRODUCTS=1 builds the Fq6 products and the sparse line product of programs for 6 lanes per pairing as
-// schoolbook sums of products under one reduction per component (n-product operations) instead of Karatsuba over
-// two-product operations.  Measured on MI355X, cycles per pairing of one wave: Miller loop 0.646 M (default, 8
-// lanes per pairing) against 0.670 M (lazy, 8 lanes: the operations come in sixes and twelves and leave a quarter
-// of the lanes idle) and 0.516 M (lazy, 6 lanes); final exponentiation 0.751 M / 0.779 M / 0.674 M.  Six lanes per
-// pairing fill a wave with ten pairings, so a batch of 65,536 is 3.2 rounds of the GPU instead of exactly 4 and takes
-// as long as 4: the default stays off; batches that are a multiple of 20,480 gain from lanes = 6 with this switch
-// on.  Only the 6-lane interpreter contains the n-product path (in the others its code and registers cost 2 %).
+// Programs for 6 lanes per pairing build the Fq6 products and the sparse line product as schoolbook sums of
+// products under one reduction per component (n-product operations) instead of Karatsuba over two-product
+// operations; BLS381_LAZY_PRODUCTS=0 turns that off.  The operations come in sixes and twelves: they fill the lanes
+// of a 6-lane group and leave a quarter of an 8-lane group idle.  Measured on MI355X (same box, ms per kernel):
+// 61,440 pairs at 6 lanes: Miller loop 10.7 (12.8 in the Karatsuba form), final exponentiation 12.3 (12.8);
+// 65,536 pairs at 8 lanes, Karatsuba form: 11.8 and 12.9 (n-product form at 8 lanes: 13.3 and 13.7).  Per pairing
+// the 6-lane programs are 1 % ahead of the 8-lane default when the batch is whole rounds of the GPU at ten pairings
+// per wave (multiples of 20,480) and behind it otherwise, so 8 lanes stay the default width.  Only the 6-lane
+// interpreter contains the n-product path (in the others its code and registers cost 2 %).
 static thread_local bool g_lazy_products = false;
 void set_lazy_products_for(int K) {
     const char* e = getenv("BLS381_LAZY_PRODUCTS");
-    g_lazy_products = K == 6 && e && atoi(e) != 0;
+    g_lazy_products = K == 6 && !(e && atoi(e) == 0);
 }
 Tower::Tower(Dag& d) : d_(d), lazy_(g_lazy_products) {}
 

@@ -513,17 +513,18 @@ def test_other_lane_group_geometries(lanes, slots):
         prep.close()
 
 
-@pytest.mark.parametrize("lanes", [6])
-def test_lazy_product_programs(lanes, monkeypatch):
-    """The programs built from n-product operations (BLS381_LAZY_PRODUCTS=1: schoolbook Fq6 products and line products,
-    one reduction per component) give the same pairings, Miller values and Fq12 products, bit for bit."""
+def test_lazy_product_programs(monkeypatch):
+    """The 6-lane programs built from n-product operations (schoolbook Fq6 products and line products, one reduction
+    per component) give the same pairings, Miller values and Fq12 products, bit for bit, as the same width with
+    BLS381_LAZY_PRODUCTS=0 (Karatsuba form)."""
     import plonky2_bls12_381_pairing_amd as B
-    ps, qs = H.random_pairs(70, 7700 + lanes)
+    ps, qs = H.random_pairs(70, 7706)
     g1, g2 = H.g1_array(ps), H.g2_array(qs)
-    with B.Context(0, lanes, 0) as c:
+    monkeypatch.setenv("BLS381_LAZY_PRODUCTS", "0")
+    with B.Context(0, 6, 0) as c:
         want, want_ml = c.pairing_batch(g1, g2), c.miller_loop_batch(g1, g2)
-    monkeypatch.setenv("BLS381_LAZY_PRODUCTS", "1")
-    with B.Context(0, lanes, 0) as c:
+    monkeypatch.delenv("BLS381_LAZY_PRODUCTS")
+    with B.Context(0, 6, 0) as c:
         assert np.array_equal(c.pairing_batch(g1, g2), want)
         assert np.array_equal(c.miller_loop_batch(g1, g2), want_ml)
         prod = c.fq12_mul_batch(want[:35], want[35:])
@@ -531,6 +532,33 @@ def test_lazy_product_programs(lanes, monkeypatch):
             assert H.fq12_from_row(prod[i]) == R.fq12_mul(H.fq12_from_row(want[i]), H.fq12_from_row(want[35 + i]))
     for i in (0, 69):
         assert H.fq12_from_row(want[i]) == R.native_pairing([ps[i]], [qs[i]])
+
+
+def test_three_chunk_batch_on_device_pointers(ctx, CO):
+    """135,000 pairs (two chunks of 65,536 and one of 3,928, which runs the 16-lane program variants) through the
+    device-pointer calls: the C oracle on a sample that touches every chunk and both sides of every boundary,
+    periodicity over the whole output, and the Miller values of the same batch against a single small call."""
+    import torch
+    from plonky2_bls12_381_pairing_amd import _lib
+    n, period = 135000, 1000
+    ps, qs = H.random_pairs(40, 6161)
+    a, b = H.g1_array(ps), H.g2_array(qs)
+    i = np.arange(period)
+    g1 = np.tile(a[i % 40], (n // period, 1))
+    g2 = np.tile(b[(i // 40) % 40], (n // period, 1))
+    dev = torch.device("cuda", 0)
+    d1 = torch.from_numpy(g1.view(np.int64)).to(dev)
+    d2 = torch.from_numpy(g2.view(np.int64)).to(dev)
+    d_out = torch.empty((n, 72), dtype=torch.int64, device=dev)
+    _lib.check(_lib.lib.bls381_pairing_batch_dev(ctx.handle, d1.data_ptr(), d2.data_ptr(), None, n, d_out.data_ptr()))
+    out = d_out.cpu().numpy().view(np.uint64)
+    probe = np.array([0, 1, 65535, 65536, 65537, 131071, 131072, 131073, n - 2, n - 1])
+    assert np.array_equal(out[probe], CO.pairing_batch(g1[probe], g2[probe]))
+    assert np.array_equal(out.reshape(n // period, period, 72), np.broadcast_to(out[:period], (n // period, period, 72)))
+    _lib.check(_lib.lib.bls381_miller_loop_batch_dev(ctx.handle, d1.data_ptr(), d2.data_ptr(), None, n, d_out.data_ptr()))
+    ml = d_out.cpu().numpy().view(np.uint64)
+    assert np.array_equal(ml[:period], ctx.miller_loop_batch(g1[:period], g2[:period]))
+    assert np.array_equal(ml.reshape(n // period, period, 72), np.broadcast_to(ml[:period], (n // period, period, 72)))
 
 
 def _bytes_array(encodings):

@@ -166,8 +166,8 @@ def test_two_pair_miller_program():
 
 def test_lazy_product_programs(monkeypatch):
     """The same pairing through the programs built from n-product operations (schoolbook Fq6 products, one reduction
-    per component; BLS381_LAZY_PRODUCTS=1, programs for 6 lanes per pairing), in the big-integer interpreter."""
-    monkeypatch.setenv("BLS381_LAZY_PRODUCTS", "1")
+    per component: the form of the programs for 6 lanes per pairing), in the big-integer interpreter; the 8-lane
+    programs and BLS381_LAZY_PRODUCTS=0 keep the Karatsuba form."""
     ps, qs = H.random_pairs(1, 4242)
     p, q = ps[0], qs[0]
     gin = [M(p[0]), M(p[1]), M(q[0][0]), M(q[0][1]), M(q[1][0]), M(q[1][1])]
@@ -178,8 +178,11 @@ def test_lazy_product_programs(monkeypatch):
         assert steps.count(S.ST_DOTN) > 100
         out = S.run_program(prog, gin)
         assert R.fq12_from_flat_ark([F(x) for x in out]) == want
-    monkeypatch.delenv("BLS381_LAZY_PRODUCTS")
-    assert S.ST_DOTN not in [S.get_program("miller", 8, 0)["hdrs"][2 * s] for s in range(50)]
+    p8 = S.get_program("miller", 8, 0)
+    assert S.ST_DOTN not in [p8["hdrs"][2 * s] for s in range(p8["nsteps"])]
+    monkeypatch.setenv("BLS381_LAZY_PRODUCTS", "0")
+    p6 = S.get_program("miller", 6, 0)
+    assert S.ST_DOTN not in [p6["hdrs"][2 * s] for s in range(p6["nsteps"])]
 
 
 def test_program_statistics():

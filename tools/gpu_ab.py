@@ -18,7 +18,7 @@ import numpy as np
 from helpers import *
 import plonky2_bls12_381_pairing_amd as B
 ps, qs = random_pairs(6, 3)
-n = 65536
+n = int(os.environ.get("AB_N", "65536"))
 g1 = np.tile(g1_array(ps), (n // 6 + 1, 1))[:n]; g2 = np.tile(g2_array(qs), (n // 6 + 1, 1))[:n]
 ctx = B.Context(0, int(os.environ.get("AB_K", "0")), int(os.environ.get("AB_SLOTS", "0")))
 for rep in range(6):
@@ -28,7 +28,7 @@ for rep in range(6):
 res = {l: ([], []) for l, _ in variants}
 for r in range(rounds):
     for l, venv in variants:
-        env = dict(os.environ, BLS381_SLICE="65536", **venv)
+        env = dict(os.environ, BLS381_SLICE="65536"); env.update(venv)
         out = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=200).stdout
         for line in out.splitlines():
             if line.startswith("T "):
