@@ -61,16 +61,17 @@ __device__ __forceinline__ F to_mont(const u32* x) {
 __device__ __forceinline__ F from_mont(const F& a) { F one = zero(); one.v[0] = 1; return mul(a, one); }
 __device__ __forceinline__ void store(u32* dst, const F& a) { for (int k = 0; k < 12; k++) dst[k] = a.v[k]; }
 
-// a^((p+1)/4): the square root of a when a is a square (p = 3 mod 4)
-__device__ __noinline__ F sqrt_candidate(const F& a) {
+// a^((p+1)/4): the square root of a when a is a square (p = 3 mod 4).  T: any of the one-lane field types
+// (their mul / sqr are found through the argument's namespace).
+template <class T> __device__ __noinline__ T sqrt_chain(const T& a) {
     // (p + 1) / 4, most significant limb first; top set bit of the top limb is bit 26
     const u32 E[12] = {0x0680447au, 0x8e5ff9a6u, 0x92c6e9edu, 0x90d2eb35u, 0xd91dd2e1u, 0x3ce144afu,
                        0xd9cc34a8u, 0x3dac3d89u, 0x07aaffffu, 0xac54ffffu, 0xee7fbfffu, 0xffffeaabu};
     // four exponent bits at a time: 378 squarings and 92 + 14 products, against 228 products bit by bit
-    F t[16];
+    T t[16];
     t[1] = a;
     for (int k = 2; k < 16; k++) t[k] = mul(t[k - 1], a);
-    F r = a;
+    T r = a;
     bool started = false;
     for (int w = 0; w < 12; w++)
         for (int s = 28; s >= 0; s -= 4) {
@@ -85,6 +86,7 @@ __device__ __noinline__ F sqrt_candidate(const F& a) {
         }
     return r;
 }
+__device__ __forceinline__ F sqrt_candidate(const F& a) { return sqrt_chain(a); }
 // sqrt in Fq: ok = false when a is not a square
 __device__ __forceinline__ F sqrt_fq(const F& a, bool& ok) {
     F r = sqrt_candidate(a);
