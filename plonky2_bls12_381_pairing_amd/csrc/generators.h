@@ -1,11 +1,12 @@
 // Values of the reference's other witness generators (square roots and inverses in Fq, Fq2, Fq6), one
 // lane per element, on canonical 12 x u32 limbs in and out as the generators read and write them
 // (from_biguint_to_fq / set_biguint_target).  Arithmetic: 12 x 32-bit Montgomery limbs (fp_mul), the
-// division-step inversion, x^((p+1)/4) for square roots (p = 3 mod 4).  Not throughput-critical: a
+// division-step inversion, x^((p+1)/4) for square roots (p = 3 mod 4; that chain on 28-bit digits).  Not throughput-critical: a
 // circuit holds a handful of these per proof.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "fp28_field.h"
 #include "fp_asm_gen.h"
 #include "fp_dev.h"
 #include "vm_kernels.h"
@@ -86,7 +87,12 @@ template <class T> __device__ __noinline__ T sqrt_chain(const T& a) {
         }
     return r;
 }
-__device__ __forceinline__ F sqrt_candidate(const F& a) { return sqrt_chain(a); }
+// (the chain runs on the 28-bit digit form, see fp28_field.h; a is in the 12-limb Montgomery form and so is the result)
+__device__ __forceinline__ F sqrt_candidate(const F& a) {
+    F r;
+    g28::to_boundary(sqrt_chain(g28::from_boundary(a.v)), r.v);
+    return r;
+}
 // sqrt in Fq: ok = false when a is not a square
 __device__ __forceinline__ F sqrt_fq(const F& a, bool& ok) {
     F r = sqrt_candidate(a);

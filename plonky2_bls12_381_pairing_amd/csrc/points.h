@@ -9,7 +9,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "fp28_field.h"
 #include "generators.h"
 
 namespace bls381 {
@@ -62,42 +61,6 @@ __device__ __forceinline__ F2 mul_b3(const F2& a) { return {times12(S(a.c0, a.c1
 __device__ __forceinline__ F four_mont() { const F o = one_mont(), t = A(o, o); return A(t, t); }
 __device__ __forceinline__ void curve_b(F& b) { b = four_mont(); }
 __device__ __forceinline__ void curve_b(F2& b) { b = {four_mont(), four_mont()}; }
-
-// ---- the same helpers on the 28-bit digit form (g28): the decoders and subgroup tests run on it
-using G = g28::F;
-using G2 = g28::F2;
-__device__ __noinline__ G M(const G& a, const G& b) { return g28::mul(a, b); }
-__device__ __noinline__ G2 M(const G2& a, const G2& b) {
-    G nb1;  // digit-wise negation: digits stay within one unit, which is all the multiplier asks
-#pragma unroll
-    for (int k = 0; k < D28; k++) nb1.v[k] = 0u - b.c1.v[k];
-    return {g28::dot2(a.c0, b.c0, a.c1, nb1), g28::dot2(a.c0, b.c1, a.c1, b.c0)};
-}
-__device__ __noinline__ G A(const G& a, const G& b) { return g28::add(a, b); }
-__device__ __noinline__ G S(const G& a, const G& b) { return g28::sub(a, b); }
-__device__ __forceinline__ G2 A(const G2& a, const G2& b) { return {A(a.c0, b.c0), A(a.c1, b.c1)}; }
-__device__ __forceinline__ G2 S(const G2& a, const G2& b) { return {S(a.c0, b.c0), S(a.c1, b.c1)}; }
-__device__ __forceinline__ G ngt(const G& a) { return S(g28::zero(), a); }
-__device__ __forceinline__ G2 ngt(const G2& a) { return {ngt(a.c0), ngt(a.c1)}; }
-__device__ __noinline__ bool is0(const G& a) { return g28::is_zero(a); }
-__device__ __forceinline__ bool is0(const G2& a) { return is0(a.c0) && is0(a.c1); }
-__device__ __forceinline__ bool same(const G& a, const G& b) { return is0(S(a, b)); }
-__device__ __forceinline__ bool same(const G2& a, const G2& b) { return same(a.c0, b.c0) && same(a.c1, b.c1); }
-template <> __device__ __forceinline__ G zero_of<G>() { return g28::zero(); }
-template <> __device__ __forceinline__ G2 zero_of<G2>() { return {g28::zero(), g28::zero()}; }
-template <> __device__ __forceinline__ G one_of<G>() { return g28::one(); }
-template <> __device__ __forceinline__ G2 one_of<G2>() { return {g28::one(), g28::zero()}; }
-// (ends with a reduction: twelve times a sum of products is the one place where values would grow past what the
-// multiplier takes)
-__device__ __forceinline__ G times12(const G& a) {
-    const G a2 = A(a, a), a4 = A(a2, a2), a8 = A(a4, a4);
-    return g28::reduced(A(a8, a4));
-}
-__device__ __forceinline__ G mul_b3(const G& a) { return times12(a); }
-__device__ __forceinline__ G2 mul_b3(const G2& a) { return {times12(S(a.c0, a.c1)), times12(A(a.c0, a.c1))}; }
-__device__ __forceinline__ G four_28() { const G o = g28::one(), t = A(o, o); return A(t, t); }
-__device__ __forceinline__ void curve_b(G& b) { b = four_28(); }
-__device__ __forceinline__ void curve_b(G2& b) { b = {four_28(), four_28()}; }
 
 // ---- homogeneous projective points; infinity = (0 : 1 : 0)
 template <class T> struct Proj { T X, Y, Z; };
@@ -189,26 +152,6 @@ __device__ __forceinline__ bool in_subgroup(const F2& x, const F2& y) {
     return peq(lhs, pneg(pmul_x(from_affine(x, y, false))));
 }
 
-__device__ __forceinline__ bool in_subgroup(const G& x, const G& y) {
-    const u32 BETA[12] = {0xfffefffeu, 0x2e01ffffu, 0x620a0002u, 0xde17d813u, 0xe6f89688u, 0xddb3a93bu,
-                          0x6a0f77eau, 0xba69c607u, 0xdf76ce51u, 0x5f19672fu, 0x00000000u, 0x00000000u};
-    const Proj<G> p = from_affine(x, y, false);
-    const Proj<G> lhs = {M(g28::from_canonical(BETA), x), y, g28::one()};
-    return peq(lhs, pneg(pmul_x(pmul_x(p))));
-}
-__device__ __forceinline__ bool in_subgroup(const G2& x, const G2& y) {
-    const u32 PSI_X_C1[12] = {0x0000aaadu, 0x8bfd0000u, 0x4f49fffdu, 0x409427ebu, 0x0fb85f9bu, 0x897d2965u,
-                              0x89759ad4u, 0xaa0d857du, 0x63d4de85u, 0xec024086u, 0x397fe699u, 0x1a0111eau};
-    const u32 PSI_Y_C0[12] = {0x121bdea2u, 0xf1ee7b04u, 0x3e67fa0au, 0x304466cfu, 0xf61eb45eu, 0xef396489u,
-                              0x30b1cf60u, 0x1c3dedd9u, 0xd77a2cd9u, 0xe2e9c448u, 0x0180a68eu, 0x135203e6u};
-    const u32 PSI_Y_C1[12] = {0xede3cc09u, 0xc81084fbu, 0x72ec05f4u, 0xee67992fu, 0x009241c5u, 0x77f76e17u,
-                              0xc2d3435eu, 0x48395dabu, 0x6bd17ffeu, 0x6831e36du, 0x37ff400bu, 0x06af0e04u};
-    const G2 cx{g28::zero(), g28::from_canonical(PSI_X_C1)}, cy{g28::from_canonical(PSI_Y_C0), g28::from_canonical(PSI_Y_C1)};
-    const G2 xc{x.c0, ngt(x.c1)}, yc{y.c0, ngt(y.c1)};
-    const Proj<G2> lhs = {M(cx, xc), M(cy, yc), one_of<G2>()};
-    return peq(lhs, pneg(pmul_x(from_affine(x, y, false))));
-}
-
 // ---- bytes <-> limbs
 // 48 big-endian bytes -> 12 little-endian u32 limbs, flag bits of byte 0 removed when `strip`
 __device__ __forceinline__ void be48_to_limbs(const uint8_t* b, u32* l, bool strip) {
@@ -236,40 +179,6 @@ __device__ __forceinline__ bool is_larger_mont(const F& y) { return is_larger(ge
 __device__ __forceinline__ bool is_larger_mont(const F2& y) {
     return is0(y.c1) ? is_larger(gen::from_mont(y.c0)) : is_larger(gen::from_mont(y.c1));
 }
-__device__ __forceinline__ bool is_larger_28(const G& y) {
-    F c;
-    g28::to_canonical(y, c.v);
-    return is_larger(c);
-}
-__device__ __forceinline__ bool is_larger_mont(const G& y) { return is_larger_28(y); }
-__device__ __forceinline__ bool is_larger_mont(const G2& y) { return is0(y.c1) ? is_larger_28(y.c0) : is_larger_28(y.c1); }
-__device__ __forceinline__ G sqrt_28(const G& a, bool& ok) {
-    const G r = gen::sqrt_chain(a);
-    ok = same(M(r, r), a);
-    return r;
-}
-// A square root of a in Fq2 = Fq[u]/(u^2 + 1) (the formulas of gen::sqrt_fq2); ok = false when a is not a square
-__device__ __noinline__ G2 sqrt_28(const G2& a, bool& ok) {
-    G2 r;
-    if (is0(a.c1)) {
-        bool sq;
-        const G s = sqrt_28(a.c0, sq);
-        r = sq ? G2{s, g28::zero()} : G2{g28::zero(), s};
-    } else {
-        bool sq;
-        const G g = sqrt_28(g28::dot2(a.c0, a.c0, a.c1, a.c1), sq);  // the norm must be a square in Fq
-        const u32 HALF[12] = {0xffffd556u, 0xdcff7fffu, 0x58a9ffffu, 0x0f55ffffu, 0x7b587b12u, 0xb3986950u,
-                              0x79c2895fu, 0xb23ba5c2u, 0x21a5d66bu, 0x258dd3dbu, 0x1cbff34du, 0x0d0088f5u};  // (p + 1) / 2
-        bool sq2;
-        const G x0 = sqrt_28(M(A(a.c0, g), g28::from_canonical(HALF)), sq2);
-        const G y = M(a.c1, g28::inv(A(x0, x0)));
-        r = sq2 ? G2{x0, y} : G2{y, x0};
-    }
-    ok = same(M(r, r), a);
-    return r;
-}
-__device__ __forceinline__ G sqrt_of(const G& a, bool& ok) { return sqrt_28(a, ok); }
-__device__ __forceinline__ G2 sqrt_of(const G2& a, bool& ok) { return sqrt_28(a, ok); }
 __device__ __forceinline__ F sqrt_of(const F& a, bool& ok) { return gen::sqrt_fq(a, ok); }
 __device__ __forceinline__ F2 sqrt_of(const F2& a, bool& ok) { return gen::sqrt_fq2(a, ok); }
 
@@ -286,12 +195,6 @@ template <class T> __device__ __forceinline__ Status solve_y(const T& x, bool so
 
 __device__ __forceinline__ void store_f(u32* dst, const F& a) { for (int k = 0; k < 12; k++) dst[k] = a.v[k]; }
 __device__ __forceinline__ F load_f(const u32* src) { F a; for (int k = 0; k < 12; k++) a.v[k] = src[k]; return a; }
-// a value of the 28-bit form as 12 boundary limbs (Montgomery factor 2^384, canonical); zeros unless `good`
-__device__ __noinline__ void store_28(u32* dst, const G& a, bool good) {
-    u32 l[12];
-    g28::to_boundary(a, l);
-    for (int k = 0; k < 12; k++) dst[k] = good ? l[k] : 0u;
-}
 
 // in: n x 48 bytes; out: n x {x, y} Montgomery limbs (zero unless status is ST_OK); status: n bytes
 __global__ __launch_bounds__(64) void g1_decompress_kernel(const uint8_t* in, int n, int check_subgroup, u32* out,
@@ -303,16 +206,17 @@ __global__ __launch_bounds__(64) void g1_decompress_kernel(const uint8_t* in, in
     u32 xl[12];
     be48_to_limbs(b, xl, true);
     Status st;
-    G x = g28::zero(), y = g28::zero();
+    F x = gen::zero(), y = gen::zero();
     if (!comp) st = ST_BAD_ENCODING;
     else if (inf) st = (!sort && limbs_zero(xl)) ? ST_INFINITY : ST_BAD_ENCODING;
     else if (!gen::below_p(xl)) st = ST_BAD_ENCODING;
     else {
-        x = g28::from_canonical(xl);
+        x = gen::to_mont(xl);
         st = solve_y(x, sort, check_subgroup != 0, y);
     }
-    store_28(out + (size_t)i * 24, x, st == ST_OK);
-    store_28(out + (size_t)i * 24 + 12, y, st == ST_OK);
+    const bool good = st == ST_OK;
+    store_f(out + (size_t)i * 24, good ? x : gen::zero());
+    store_f(out + (size_t)i * 24 + 12, good ? y : gen::zero());
     status[i] = st;
 }
 // in: n x 96 bytes (x.c1 then x.c0); out: n x {x.c0, x.c1, y.c0, y.c1}
@@ -326,18 +230,19 @@ __global__ __launch_bounds__(64) void g2_decompress_kernel(const uint8_t* in, in
     be48_to_limbs(b, x1, true);
     be48_to_limbs(b + 48, x0, false);
     Status st;
-    G2 x = zero_of<G2>(), y = zero_of<G2>();
+    F2 x = zero_of<F2>(), y = zero_of<F2>();
     if (!comp) st = ST_BAD_ENCODING;
     else if (inf) st = (!sort && limbs_zero(x0) && limbs_zero(x1)) ? ST_INFINITY : ST_BAD_ENCODING;
     else if (!gen::below_p(x0) || !gen::below_p(x1)) st = ST_BAD_ENCODING;
     else {
-        x = {g28::from_canonical(x0), g28::from_canonical(x1)};
+        x = {gen::to_mont(x0), gen::to_mont(x1)};
         st = solve_y(x, sort, check_subgroup != 0, y);
     }
     const bool good = st == ST_OK;
+    const F z = gen::zero();
     u32* o = out + (size_t)i * 48;
-    store_28(o, x.c0, good); store_28(o + 12, x.c1, good);
-    store_28(o + 24, y.c0, good); store_28(o + 36, y.c1, good);
+    store_f(o, good ? x.c0 : z); store_f(o + 12, good ? x.c1 : z);
+    store_f(o + 24, good ? y.c0 : z); store_f(o + 36, good ? y.c1 : z);
     status[i] = st;
 }
 // points: n x {x, y} Montgomery limbs, inf: n bytes (may be null) -> n x 48 bytes
