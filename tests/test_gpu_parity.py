@@ -334,6 +334,18 @@ def test_pairing_witness_trace_256_proofs(ctx, CO, monkeypatch):
     assert np.array_equal(d_out.cpu().numpy().view(np.uint32).reshape(trace.shape), trace)
 
 
+@pytest.mark.parametrize("cache,lpp", [("0", "16"), ("16", "16"), ("256", "32"), ("1024", "64")])
+def test_witness_kernel_geometries(ctx, cache, lpp, monkeypatch):
+    """The witness kernel with no LDS row cache, a small one and large ones, at 16, 32 and 64 lanes per proof: the same
+    trace bytes as the default (32 rows, 16 lanes), which test_pairing_witness_trace checks against the CPU replay."""
+    ps, qs = H.random_pairs(5, 9191)
+    g1, g2 = H.g1_array(ps), H.g2_array(qs)
+    want = ctx.pairing_witness_batch(g1, g2)
+    monkeypatch.setenv("BLS381_WIT_CACHE", cache)
+    monkeypatch.setenv("BLS381_WIT_LPP", lpp)
+    assert np.array_equal(ctx.pairing_witness_batch(g1, g2), want)
+
+
 def test_pairing_witness_auxiliary_values(ctx):
     """The gadgets' auxiliary values beside the trace (mul quotients, add/sub/neg carry bytes, the inv row's quotient)
     against the CPU replay, which forms them from Python integers: a * b == q * p + r for every one of the 70,656
