@@ -186,6 +186,9 @@ SFq2 Tower::sqr(const SFq2& a) {
     if (a.c1.is_zero()) return {mul(a.c0, a.c0), SZERO};
     if (a.c0.is_zero()) return {neg(mul(a.c1, a.c1)), SZERO};
     // two-product forms, no sums around them: c0 = a0 a0 - a1 a1, c1 = a0 a1 + a0 a1
+    // (as two single products (a0 + a1)(a0 - a1) and a0 (a1 + a1) the squarings would multiply less, but single
+    // products ride in two-product steps at a two-product's cost unless eight of them are ready at once, which the
+    // Miller loop's twenty per iteration rarely are: 11 product-only steps of 1,315, and 500 more sums)
     SFp a0 = mat(a.c0), a1 = mat(a.c1);
     SFp c0{d_.dot2(a0.id, a0.id, a1.id, a1.id, /*neg_d=*/true)};
     SFp c1{d_.dot2(a0.id, a1.id, a0.id, a1.id)};
