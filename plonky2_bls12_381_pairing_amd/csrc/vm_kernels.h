@@ -110,35 +110,22 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
     u32 nx = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)cur.x);
     u32 ny = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)cur.y);
     u32 nz = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)cur.z);
-    u32 nw = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)cur_hi.y);  // the word of the carried copies
-    // The next step's descriptor words travel nx -> px -> dx: they are taken out of the registers the permutes write
-    // (px = nx) in the middle of a step, right after the step has waited for its own operand loads, which were issued
-    // after the permutes: no wait of their own.  Taken at the end of the step instead, the read would have to wait
-    // for everything the step issued since, its result stores included.
-    u32 px = nx, py = ny, pz = nz, pw = nw;
-#define BLS381_TAKE_NEXT()                                         \
-    do {                                                           \
-        px = nx; py = ny; pz = nz; pw = nw;                        \
-        asm volatile("" : "+v"(px), "+v"(py), "+v"(pz), "+v"(pw)); \
-    } while (0)
     for (int b = 0; b < A.nblocks; b++) {
       const uint4 ahead = bptr[(size_t)min(b + 2, last_block) * 128];
       const uint4 ahead_hi = bptr[(size_t)min(b + 2, last_block) * 128 + 64];
       const int nj = min((int)SPB, A.nsteps - s);  // steps of this block
       for (int j = 0; j < nj; j++, s++) {
-        const u32 dx = px, dy = py, dz = pz, dw = pw;
+        const u32 dx = nx, dy = ny, dz = nz;
         if (j + 1 < SPB) {  // a branch, not a select: the next block's registers are touched once per block only
             const int from = ((j + 1) * K + role) * 4;
             nx = (u32)__builtin_amdgcn_ds_bpermute(from, (int)cur.x);
             ny = (u32)__builtin_amdgcn_ds_bpermute(from, (int)cur.y);
             nz = (u32)__builtin_amdgcn_ds_bpermute(from, (int)cur.z);
-            nw = (u32)__builtin_amdgcn_ds_bpermute(from, (int)cur_hi.y);
         } else {
             asm volatile("" ::: "memory");
             nx = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)nxt.x);
             ny = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)nxt.y);
             nz = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)nxt.z);
-            nw = (u32)__builtin_amdgcn_ds_bpermute(role * 4, (int)nxt_hi.y);
         }
         const int self = (j * K + role) * 4;
         const u32 hx = (u32)__builtin_amdgcn_readfirstlane((int)dx);  // step-wide fields
@@ -162,6 +149,7 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
         // loads later then never waits for these stores).
         u32 pf[D28];  // deliberately not initialised: a merge with constants would make the compiler copy
                       // the loaded registers, and so wait for the loads, right where they are issued
+        u32 dw = 0;   // the descriptor word of the carried copies, fetched only by steps that carry any
         const bool carries = type != ST_COPY && (hx & (3u << 23));  // (a copy step's destination field extends over these bits)
         // Descriptor words beyond the first three are fetched here, before the step issues any load from global
         // memory: the block's registers came from global loads themselves, and a wait for them placed after the
@@ -169,6 +157,10 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
         u32 d3 = 0, d4 = 0;  // sums: terms 4..6; multiplier steps: the operands' third terms
         if (hx & (1u << 10)) d3 = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur.w);
         if (hx & (1u << 11)) d4 = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur_hi.x);
+        if (carries) {
+            dw = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur_hi.y);
+            asm volatile("" : "+v"(dw));  // nothing derived from dw is computed (and waited for) by steps that carry nothing
+        }
         if (carries && (hx & (1u << 23))) {
             // a fill may read what a spill of an earlier step wrote: drain the wave's stores first
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -263,7 +255,6 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             for (int i = 0; i < D28; i++) r[i] = (u32)acc[i];
             if (flags & 2u) reduce28(r);  // sweeps as well
             else if (flags) normalise28(r);
-            BLS381_TAKE_NEXT();
             lds_store(dst, r);
         } else if (K == 6 && type == ST_DOTN) {  // (compiled into the 6-lane interpreter only)
             // dst = (sum over t of a_t * (+-b_t)) / 2^392 with one reduction.  Operand scanning: every product of
@@ -315,7 +306,6 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                 col[k + 1] += col[k] >> 28;
             }
             r[D28 - 1] = (u32)col[2 * D28 - 1];
-            BLS381_TAKE_NEXT();
             lds_store(dst, r);
         } else if (type == ST_DOT2 || type == ST_FMUL) {
             // operands: a, b (, c, d), each a signed sum of up to max_terms slots added up as they are loaded
@@ -372,7 +362,6 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                 }
                 fp28_mul(a, b, r);
             }
-            BLS381_TAKE_NEXT();
             lds_store(dst, r);
         } else {  // ST_COPY: every lane reads before any lane writes
             const u32 kind = (dx >> 5) & 7u;
@@ -413,7 +402,6 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             // with waits that also stall on unrelated stores and descriptor prefetches.
             asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
                               "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]));
-            BLS381_TAKE_NEXT();
             if (on) {
                 if (kind <= CK_CONST) {
                     lds_store(dst, v);
