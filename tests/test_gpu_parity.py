@@ -1038,6 +1038,19 @@ def test_workspace_reservation(CO):
     assert np.array_equal(got[6:12], got[:6]) and np.array_equal(small.cpu().numpy().view(np.uint64), got[:100])
 
 
+def test_plain_c_caller(tmp_path):
+    """examples/pairing_c_abi.c, built with gcc alone, prints e(G1, G2): the same limbs as the oracle's pairing of the
+    generators (whose first coefficient is the public constant of zkcrypto's Gt generator)."""
+    import subprocess
+    from test_host_cpu import _build_c_example
+    exe = _build_c_example(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-500:]
+    got = [int("".join(line.split()[1:]), 16) for line in out.stdout.strip().splitlines()]
+    want = R.fq12_flatten_ark(R.native_pairing([R.G1_GEN], [R.G2_GEN]))
+    assert got == [x * (1 << 384) % R.P for x in want]
+
+
 def test_argument_errors_on_a_live_context(ctx):
     """NULL buffers, sizes past the documented limits and bad selectors: BLS381_ERR_INVALID, nothing launched,
     and the context keeps working afterwards."""

@@ -218,3 +218,29 @@ def test_one_hip_runtime_in_either_import_order():
     assert out.returncode == 0, out.stderr[-500:]
     libs = eval(out.stdout.strip().splitlines()[-1])
     assert len(libs) == 1 and "torch" in libs[0], libs
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "pairing_c_abi")
+    libdir = os.path.join(root, "plonky2_bls12_381_pairing_amd")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+           os.path.join(root, "examples", "pairing_c_abi.c"), "-L", libdir, "-lbls381_hip", "-Wl,-rpath," + libdir, "-o", exe]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-800:]
+    return exe
+
+
+def test_header_is_plain_c_and_the_c_example_links(tmp_path):
+    """include/bls381_hip.h compiles as strict C99 and as C++, and the plain-C example builds and links against the
+    shared library with nothing but gcc."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "bls381_hip.h"\nint main(void) { bls381_ctx* c = 0; return bls381_ctx_create(&c, 0) == 0 ? 0 : 1; }\n')
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only"],
+                ["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++"]):
+        out = subprocess.run(cmd + ["-I", os.path.join(root, "include"), str(src)], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-800:]
+    _build_c_example(tmp_path)
