@@ -237,6 +237,11 @@ int bls381_debug_fp_mul(bls381_ctx*, const uint32_t* a, const uint32_t* b, size_
  * Fq12::inverse (/root/reference/src/native/final_exponentiation.rs:9, through ark-ff) bottoms out
  * in, exposed for direct testing. */
 int bls381_debug_fp_inverse(bls381_ctx*, const uint32_t* a, size_t n, uint32_t* out, uint8_t* is_zero);
+/* The witness kernel keeps `cache_rows` (0..128) trace rows per proof in LDS, filled and read according to a plan
+ * made on the host for the number of lanes that serve one proof (a divisor of 64).  Builds that plan and replays it:
+ * out = {operand reads of trace rows, reads the plan serves from LDS, plan violations (must be 0), operations}.
+ * Host-only: needs no GPU. */
+int bls381_debug_witness_cache_plan(int lanes_per_proof, int cache_rows, uint64_t out[4]);
 /* The interpreter's constant table: C_COUNT rows of 16 u32 (14 digits of 28 bits, zero padded). */
 int bls381_debug_constants(uint32_t* out, size_t capacity_fp);
 /* ---- the other witness generators of the reference --------------------------------------------

@@ -1468,6 +1468,49 @@ extern "C" int bls381_debug_program(const char* which, int K, int lds_slots, uin
     }
     return 0;
 }
+// The witness kernel's row-cache plan for (lanes per proof, cache rows), replayed on the host: every read the plan
+// sends to a cache entry must find its row there, and no two results of one iteration may share an entry.
+extern "C" int bls381_debug_witness_cache_plan(int lanes_per_proof, int cache_rows, uint64_t out[4]) {
+    if (!out) return fail(BLS381_ERR_INVALID, "NULL argument");
+    if (lanes_per_proof < 1 || lanes_per_proof > 64 || 64 % lanes_per_proof) return fail(BLS381_ERR_INVALID, "lanes per proof must divide 64");
+    if (cache_rows < 0 || cache_rows > (int)WCACHE_MAX_ROWS) return fail(BLS381_ERR_INVALID, "cache rows out of range");
+    const WitnessProgram& P = witness_program();
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (int ph = 0; ph < 2; ph++) {
+        size_t reads = 0, hits = 0;
+        const std::vector<WitnessOp> ops = plan_row_cache(P, ph, lanes_per_proof, cache_rows, &reads, &hits);
+        out[0] += reads; out[1] += hits; out[3] += ops.size();
+        std::vector<int64_t> entry(WCACHE_MAX_ROWS, -1);
+        const auto& ls = P.level_start[ph];
+        for (size_t l = 0; l + 1 < ls.size(); l++)
+            for (uint32_t i = ls[l]; i < ls[l + 1]; i += (uint32_t)lanes_per_proof) {
+                const uint32_t e = std::min(i + (uint32_t)lanes_per_proof, ls[l + 1]);
+                for (uint32_t j = i; j < e; j++) {
+                    const uint32_t kind = ops[j].dst >> 28;
+                    const uint32_t refs[2] = {ops[j].a, ops[j].b};
+                    for (int k = 0; k < (kind == WK_NEG || kind == WK_INV ? 1 : 2); k++) {
+                        if ((refs[k] >> 30) != 0) { if (refs[k] & WCACHE_FLAG) out[2]++; continue; }
+                        if (!(refs[k] & WCACHE_FLAG)) continue;
+                        const uint32_t sl = (refs[k] >> WCACHE_SLOT_SHIFT) & WCACHE_SLOT_MASK;
+                        if ((int)sl >= cache_rows || entry[sl] != (int64_t)(refs[k] & WROW_MASK)) out[2]++;
+                    }
+                    if ((ops[j].dst & WROW_MASK) != (P.ops[ph][j].dst & WROW_MASK) || (ops[j].dst >> 28) != (P.ops[ph][j].dst >> 28) ||
+                        ((ops[j].a ^ P.ops[ph][j].a) & ~(WCACHE_FLAG | (WCACHE_SLOT_MASK << WCACHE_SLOT_SHIFT))) ||
+                        ((ops[j].b ^ P.ops[ph][j].b) & ~(WCACHE_FLAG | (WCACHE_SLOT_MASK << WCACHE_SLOT_SHIFT))))
+                        out[2]++;
+                }
+                std::vector<uint32_t> written;
+                for (uint32_t j = i; j < e; j++) {
+                    if (!(ops[j].dst & WCACHE_FLAG)) continue;
+                    const uint32_t sl = (ops[j].dst >> WCACHE_SLOT_SHIFT) & WCACHE_SLOT_MASK;
+                    if ((int)sl >= cache_rows || std::find(written.begin(), written.end(), sl) != written.end()) out[2]++;
+                    written.push_back(sl);
+                    entry[sl] = ops[j].dst & WROW_MASK;
+                }
+            }
+    }
+    return 0;
+}
 extern "C" int bls381_debug_constants(uint32_t* out, size_t capacity_fp) {
     if (!out || capacity_fp < C_COUNT) return fail(BLS381_ERR_INVALID, "buffer too small");
     std::vector<uint32_t> c;

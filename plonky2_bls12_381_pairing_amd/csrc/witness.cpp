@@ -355,6 +355,79 @@ WitnessProgram build_program() {
 
 }  // namespace
 
+// Row cache plan.  The kernel gives every proof `cache_rows` rows of LDS; which finished rows go there, and which
+// operand reads find their row there, is decided here, once, because the program is the same for every proof:
+// the lanes of a proof take the operations of a level `lpp` at a time (one iteration: all its reads, then all its
+// writes), and walking the iterations in order with every row's later reads known, a finished row replaces the
+// resident row whose next read lies furthest ahead (never one placed in the same iteration: two lanes would
+// write one entry).  Three operand reads in four then come from LDS at 32 rows, where a cache addressed by row
+// number holds one in three.  The operations come back with the cache fields of WitnessOp filled in.
+std::vector<WitnessOp> plan_row_cache(const WitnessProgram& P, int phase, int lpp, int cache_rows, size_t* reads_out,
+                                      size_t* hits_out) {
+    std::vector<WitnessOp> ops = P.ops[phase];
+    const auto& ls = P.level_start[phase];
+    size_t reads = 0, hits = 0;
+    auto n_operands = [](const WitnessOp& o) { const uint32_t k = o.dst >> 28; return k == WK_NEG || k == WK_INV ? 1 : 2; };
+    // iteration number of every operation
+    std::vector<uint32_t> iter_of(ops.size());
+    uint32_t it = 0;
+    for (size_t l = 0; l + 1 < ls.size(); l++)
+        for (uint32_t i = ls[l]; i < ls[l + 1]; i += (uint32_t)lpp, it++)
+            for (uint32_t j = i; j < std::min(i + (uint32_t)lpp, ls[l + 1]); j++) iter_of[j] = it;
+    std::vector<std::vector<uint32_t>> uses(P.n_rows);  // iterations that read a row, ascending
+    for (size_t j = 0; j < ops.size(); j++) {
+        uint32_t* refs[2] = {&ops[j].a, &ops[j].b};
+        for (int k = 0; k < n_operands(ops[j]); k++)
+            if ((*refs[k] >> 30) == 0) { uses[*refs[k] & WROW_MASK].push_back(iter_of[j]); reads++; }
+    }
+    if (cache_rows > 0) {
+        std::vector<size_t> cursor(P.n_rows, 0);
+        auto next_use = [&](uint32_t row, uint32_t now) -> uint32_t {
+            size_t& c = cursor[row];
+            while (c < uses[row].size() && uses[row][c] <= now) c++;
+            return c < uses[row].size() ? uses[row][c] : 0xffffffffu;
+        };
+        std::vector<int> slot_of(P.n_rows, -1);
+        std::vector<int64_t> row_in(cache_rows, -1), placed_at(cache_rows, -1);
+        for (size_t j = 0; j < ops.size();) {
+            size_t e = j;
+            while (e < ops.size() && iter_of[e] == iter_of[j]) e++;
+            const uint32_t now = iter_of[j];
+            for (size_t q = j; q < e; q++) {
+                uint32_t* refs[2] = {&ops[q].a, &ops[q].b};
+                for (int k = 0; k < n_operands(ops[q]); k++) {
+                    if ((*refs[k] >> 30) != 0) continue;
+                    const int sl = slot_of[*refs[k] & WROW_MASK];
+                    if (sl >= 0) { *refs[k] |= WCACHE_FLAG | ((uint32_t)sl << WCACHE_SLOT_SHIFT); hits++; }
+                }
+            }
+            for (size_t q = j; q < e; q++) {
+                const uint32_t row = ops[q].dst & WROW_MASK;
+                const uint32_t nu = next_use(row, now);
+                if (nu == 0xffffffffu) continue;
+                int victim = -1;
+                uint32_t furthest = 0;
+                for (int sl = 0; sl < cache_rows; sl++) {
+                    if (placed_at[sl] == (int64_t)now) continue;
+                    const uint32_t u = row_in[sl] < 0 ? 0xffffffffu : next_use((uint32_t)row_in[sl], now);
+                    if (victim < 0 || u > furthest) { victim = sl; furthest = u; }
+                    if (u == 0xffffffffu) break;
+                }
+                if (victim < 0 || furthest <= nu) continue;
+                if (row_in[victim] >= 0) slot_of[row_in[victim]] = -1;
+                row_in[victim] = row;
+                placed_at[victim] = now;
+                slot_of[row] = victim;
+                ops[q].dst |= WCACHE_FLAG | ((uint32_t)victim << WCACHE_SLOT_SHIFT);
+            }
+            j = e;
+        }
+    }
+    if (reads_out) *reads_out = reads;
+    if (hits_out) *hits_out = hits;
+    return ops;
+}
+
 const WitnessProgram& witness_program() {
     static WitnessProgram P = build_program();
     return P;
@@ -364,7 +437,7 @@ const WitnessProgram& witness_program() {
 __device__ __forceinline__ void w_load(const u32* base, u32 ref, const u32* T, const u32* consts, const u32* inputs,
                                        u32* x) {
     const u32* p;
-    u32 sp = ref >> 30, idx = ref & WREF_MASK;
+    u32 sp = ref >> 30, idx = ref & WROW_MASK;
     if (sp == 0) p = T + (size_t)idx * 12;
     else if (sp == 1) p = consts + (size_t)idx * 12;
     else p = inputs + (size_t)idx * 12;
@@ -377,12 +450,12 @@ __device__ __forceinline__ void w_load(const u32* base, u32 ref, const u32* T, c
 
 // lpp lanes per proof: a workgroup of blockDim.x lanes serves blockDim.x / lpp proofs side by side.
 // Nine operand reads in ten name a row written at most 256 rows earlier, six in ten one at most 64 rows earlier,
-// but with thousands of proofs in flight those rows have left every cache by then.  So each proof keeps its last
-// rows in LDS as well: `cache_rows` entries (a power of two, 0 = none) of 12 words, direct-mapped by row number,
-// beside a tag array holding row + 1.  A read whose tag matches comes from LDS, any other from the trace in global
-// memory, which always holds every finished row.  The lanes of a proof sit in one wave (lpp divides 64) and a wave
-// executes its LDS instructions in order, all lanes together: every lane's reads of an iteration precede every
-// lane's writes of it, so an entry is never seen half replaced.
+// but with thousands of proofs in flight those rows have left every hardware cache by then.  So each proof keeps
+// `cache_rows` rows in LDS as well, managed by the plan in the operations (plan_row_cache): a reference with
+// WCACHE_FLAG reads its row from the named entry, a result with the flag is written there besides the trace in
+// global memory, which always holds every finished row.  The lanes of a proof sit in one wave (lpp divides 64) and
+// a wave executes its LDS instructions in order, all lanes together: every lane's reads of an iteration precede
+// every lane's writes of it, as the plan assumes.
 __global__ __launch_bounds__(256) void witness_kernel(const WitnessOp* ops, const u32* level_start, int nlevels,
                                                       u32* trace, size_t rows, const u32* consts, const u32* inputs,
                                                       int lpp, int nproofs, int cache_rows) {
@@ -393,17 +466,10 @@ __global__ __launch_bounds__(256) void witness_kernel(const WitnessOp* ops, cons
     u32* T = trace + (size_t)(live ? proof : 0) * rows * 12;
     const u32* in = inputs + (size_t)(live ? proof : 0) * 6 * 12;
     const u32 P[12] = BLS381_P_LIMBS;
-    // this proof's part of the cache: cache_rows x 3 uint4 of data, then (after all proofs' data) the tags
-    const int per_block = blockDim.x / lpp, pl = threadIdx.x / lpp;
-    uint4* cdata = wcache + (size_t)pl * cache_rows * 3;
-    u32* ctag = reinterpret_cast<u32*>(wcache + (size_t)per_block * cache_rows * 3) + (size_t)pl * cache_rows;
-    const u32 cmask = (u32)cache_rows - 1u;
-    for (int i = sub; i < cache_rows; i += lpp) ctag[i] = 0;
-    __syncthreads();
+    uint4* cdata = wcache + (size_t)(threadIdx.x / lpp) * cache_rows * 3;  // this proof's entries: 3 uint4 each
     auto load = [&](u32 ref, u32* x) {
-        const u32 sp = ref >> 30, idx = ref & WREF_MASK;
-        if (cache_rows && sp == 0 && ctag[idx & cmask] == idx + 1u) {
-            const uint4* q = cdata + (size_t)(idx & cmask) * 3;
+        if ((ref >> 30) == 0 && (ref & WCACHE_FLAG)) {
+            const uint4* q = cdata + (size_t)((ref >> WCACHE_SLOT_SHIFT) & WCACHE_SLOT_MASK) * 3;
             uint4 a = q[0], b = q[1], c = q[2];
             x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
             x[8] = c.x; x[9] = c.y; x[10] = c.z; x[11] = c.w;
@@ -415,7 +481,7 @@ __global__ __launch_bounds__(256) void witness_kernel(const WitnessOp* ops, cons
         const u32 lo = level_start[l], hi = level_start[l + 1];
         for (u32 i = lo + sub; live && i < hi; i += lpp) {
             const WitnessOp op = ops[i];
-            const u32 kind = op.dst >> 28, row = op.dst & 0x0fffffffu;
+            const u32 kind = op.dst >> 28, row = op.dst & WROW_MASK;
             u32 a[12], b[12], r[12];
             load(op.a, a);
             if (kind == WK_INV) {
@@ -459,19 +525,18 @@ __global__ __launch_bounds__(256) void witness_kernel(const WitnessOp* ops, cons
             d[0] = make_uint4(r[0], r[1], r[2], r[3]);
             d[1] = make_uint4(r[4], r[5], r[6], r[7]);
             d[2] = make_uint4(r[8], r[9], r[10], r[11]);
-            if (cache_rows) {
-                // (the compiler must not move these stores above the reads of this iteration, nor the next
-                // iteration's reads above them: other lanes of the wave read what this lane replaces)
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                uint4* q = cdata + (size_t)(row & cmask) * 3;
+            // (the compiler must not move this store above the reads of this iteration, nor the next iteration's
+            // reads above it: other lanes of the wave read what this lane replaces)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (op.dst & WCACHE_FLAG) {
+                uint4* q = cdata + (size_t)((op.dst >> WCACHE_SLOT_SHIFT) & WCACHE_SLOT_MASK) * 3;
                 q[0] = make_uint4(r[0], r[1], r[2], r[3]);
                 q[1] = make_uint4(r[4], r[5], r[6], r[7]);
                 q[2] = make_uint4(r[8], r[9], r[10], r[11]);
-                ctag[row & cmask] = row + 1u;
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
             }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
     }
@@ -515,7 +580,7 @@ __global__ void witness_aux_kernel(const WitnessOp* ops, int nops, const u32* mu
     if (t >= (long)nproofs * nops) return;
     const int proof = (int)(t / nops);
     const WitnessOp op = ops[t % nops];
-    const u32 kind = op.dst >> 28, row = op.dst & 0x0fffffffu;
+    const u32 kind = op.dst >> 28, row = op.dst & WROW_MASK;
     const u32* T = trace + (size_t)proof * rows * 12;
     const u32* in = inputs + (size_t)proof * 6 * 12;
     const u32 P[12] = BLS381_P_LIMBS;
@@ -650,13 +715,26 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
     }
     if (const char* e = getenv("BLS381_WIT_BLOCK")) block = atoi(e);
     if (const char* e = getenv("BLS381_WIT_LPP")) lpp = atoi(e);
-    int cache_rows = 32;  // rows per proof kept in LDS, see witness_kernel (measured, proofs/s at 16 lanes per proof: none 191 k, 16 rows 196 k, 32 rows 203 k, 64 rows 153 k: larger caches cost occupancy)
+    // rows per proof kept in LDS, see witness_kernel and plan_row_cache (measured, proofs/s at 16 lanes per proof and
+    // 16,384 proofs in flight: none 190 k, 16 rows 218 k, 32 rows 234 k, 48 rows 242 k, 64 rows 205 k: sixteen
+    // one-wave workgroups of four proofs per CU hold 144 KiB of LDS at 48 rows; more costs occupancy)
+    int cache_rows = 48;
     if (const char* e = getenv("BLS381_WIT_CACHE")) cache_rows = atoi(e);
     if (block < 1 || block > 256 || block % 64) { err = "BLS381_WIT_BLOCK must be 64, 128, 192 or 256"; return -1; }
     if (lpp < 1 || lpp > 64 || 64 % lpp) { err = "BLS381_WIT_LPP must divide 64"; return -1; }
-    if (cache_rows < 0 || cache_rows > 1024 || (cache_rows & (cache_rows - 1))) { err = "BLS381_WIT_CACHE must be 0 or a power of two up to 1024"; return -1; }
-    const size_t cache_bytes = (size_t)(block / lpp) * cache_rows * 52;
+    if (cache_rows < 0 || cache_rows > (int)WCACHE_MAX_ROWS) { err = "BLS381_WIT_CACHE must be in 0..128"; return -1; }
+    const size_t cache_bytes = (size_t)(block / lpp) * cache_rows * 48;
     if (cache_bytes > 64 * 1024) { err = "BLS381_WIT_CACHE: more than 64 KiB of LDS per workgroup"; return -1; }
+    if (plan_lpp_ != lpp || plan_rows_ != cache_rows) {
+        for (int ph = 0; ph < 2; ph++) {
+            const std::vector<WitnessOp> planned = plan_row_cache(P, ph, lpp, cache_rows);
+            if (!d_plan_[ph]) WCHK(hipMalloc((void**)&d_plan_[ph], planned.size() * sizeof(WitnessOp)));
+            WCHK(hipStreamSynchronize(stream));  // an earlier pass may still read the plan being replaced
+            WCHK(hipMemcpy(d_plan_[ph], planned.data(), planned.size() * sizeof(WitnessOp), hipMemcpyHostToDevice));
+        }
+        plan_lpp_ = lpp;
+        plan_rows_ = cache_rows;
+    }
     const int per_block = block / lpp;
     for (size_t off = 0; off < n; off += CH) {
         int m = (int)std::min(CH, n - off);
@@ -673,7 +751,7 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         WCHK(hipMemcpyAsync(d_g2, g2 + off * 24, (size_t)m * 192, in_kind, stream));
         hipLaunchKernelGGL(witness_inputs_kernel, dim3((m * 6 + 63) / 64), dim3(64), 0, stream, d_g1, d_g2, (u32*)d_inputs_, m);
         WCHK(hipGetLastError());
-        hipLaunchKernelGGL(witness_kernel, dim3((m + per_block - 1) / per_block), dim3(block), cache_bytes, stream, d_ops_[0], d_levels_[0],
+        hipLaunchKernelGGL(witness_kernel, dim3((m + per_block - 1) / per_block), dim3(block), cache_bytes, stream, d_plan_[0], d_levels_[0],
                            (int)P.level_start[0].size() - 1, d_trace_m, P.n_rows, d_consts_, (const u32*)d_inputs_, lpp, m, cache_rows);
         WCHK(hipGetLastError());
         u32* d_x = (u32*)d_x_;
@@ -686,7 +764,7 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         hipLaunchKernelGGL(witness_scatter_kernel, dim3((m * 12 + 63) / 64), dim3(64), 0, stream, d_trace_m, P.n_rows,
                            P.gen_start, d_inv, m);
         WCHK(hipGetLastError());
-        hipLaunchKernelGGL(witness_kernel, dim3((m + per_block - 1) / per_block), dim3(block), cache_bytes, stream, d_ops_[1], d_levels_[1],
+        hipLaunchKernelGGL(witness_kernel, dim3((m + per_block - 1) / per_block), dim3(block), cache_bytes, stream, d_plan_[1], d_levels_[1],
                            (int)P.level_start[1].size() - 1, d_trace_m, P.n_rows, d_consts_, (const u32*)d_inputs_, lpp, m, cache_rows);
         WCHK(hipGetLastError());
         if (aux && (aux->mul_quot || aux->carry || aux->inv_quot)) {
@@ -727,7 +805,12 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
 }
 
 void WitnessDevice::release() {
-    for (int ph = 0; ph < 2; ph++) { if (d_ops_[ph]) (void)hipFree(d_ops_[ph]); if (d_levels_[ph]) (void)hipFree(d_levels_[ph]); d_ops_[ph] = nullptr; d_levels_[ph] = nullptr; }
+    for (int ph = 0; ph < 2; ph++) {
+        for (void* p : {(void*)d_ops_[ph], (void*)d_plan_[ph], (void*)d_levels_[ph]}) if (p) (void)hipFree(p);
+        d_ops_[ph] = d_plan_[ph] = nullptr;
+        d_levels_[ph] = nullptr;
+    }
+    plan_lpp_ = plan_rows_ = -1;
     for (void* p : {(void*)d_consts_, (void*)d_inv_refs_, (void*)d_mul_index_, d_trace_, d_inputs_, d_x_, d_g_, d_aux_}) if (p) (void)hipFree(p);
     d_consts_ = nullptr; d_inv_refs_ = nullptr; d_mul_index_ = nullptr; d_trace_ = d_inputs_ = d_x_ = d_g_ = d_aux_ = nullptr;
     trace_bytes_ = inputs_bytes_ = x_bytes_ = g_bytes_ = aux_bytes_ = 0;

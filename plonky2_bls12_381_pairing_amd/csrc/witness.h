@@ -22,11 +22,15 @@ namespace bls381 {
 
 enum WitnessKind : uint8_t { WK_ADD = 0, WK_SUB = 1, WK_MUL = 2, WK_NEG = 3, WK_INV = 4, WK_GEN = 5 };
 
-// operand reference: bits 30..31 = space (0 trace row, 1 constant, 2 circuit input), bits 0..29 = index
+// operand reference: bits 30..31 = space (0 trace row, 1 constant, 2 circuit input), bits 0..17 = index.
+// In the operations handed to the kernel (plan_row_cache) a row reference may also say that the row sits in the
+// proof's LDS row cache: bit 25 set, entry number in bits 18..24.  WitnessOp::dst carries the same fields for the
+// row an operation produces: bit 25 = the result is kept in the cache entry of bits 18..24 as well.
 enum { WREF_ROW = 0u << 30, WREF_CONST = 1u << 30, WREF_INPUT = 2u << 30, WREF_MASK = (1u << 30) - 1 };
+enum : uint32_t { WROW_MASK = (1u << 18) - 1, WCACHE_SLOT_SHIFT = 18, WCACHE_SLOT_MASK = 0x7f, WCACHE_FLAG = 1u << 25, WCACHE_MAX_ROWS = 128 };
 
 struct WitnessOp {
-    uint32_t dst;   // row index | kind << 28
+    uint32_t dst;   // row index (bits 0..17) | cache fields | kind << 28
     uint32_t a, b;  // operand references (b unused for neg / inv)
 };
 
@@ -55,6 +59,10 @@ struct WitnessAux {
     uint32_t* inv_quot;  // n x 24
 };
 const WitnessProgram& witness_program();
+// The operations of one phase with their row-cache fields filled in for `lpp` lanes per proof and `cache_rows` cache
+// entries per proof (0: every read from the trace); optionally the number of row reads and how many the cache serves.
+std::vector<WitnessOp> plan_row_cache(const WitnessProgram& P, int phase, int lpp, int cache_rows, size_t* reads_out = nullptr,
+                                      size_t* hits_out = nullptr);
 
 struct bls381_ctx_fwd;
 
@@ -71,7 +79,9 @@ class WitnessDevice {
 
    private:
     bool uploaded_ = false;
-    WitnessOp* d_ops_[2] = {nullptr, nullptr};
+    WitnessOp* d_ops_[2] = {nullptr, nullptr};   // as built (the auxiliary-value kernel reads these)
+    WitnessOp* d_plan_[2] = {nullptr, nullptr};  // with the row-cache plan for (plan_lpp_, plan_rows_)
+    int plan_lpp_ = -1, plan_rows_ = -1;
     uint32_t* d_levels_[2] = {nullptr, nullptr};
     uint32_t* d_consts_ = nullptr;
     uint32_t* d_inv_refs_ = nullptr;

@@ -334,10 +334,11 @@ def test_pairing_witness_trace_256_proofs(ctx, CO, monkeypatch):
     assert np.array_equal(d_out.cpu().numpy().view(np.uint32).reshape(trace.shape), trace)
 
 
-@pytest.mark.parametrize("cache,lpp", [("0", "16"), ("16", "16"), ("256", "32"), ("1024", "64")])
+@pytest.mark.parametrize("cache,lpp", [("0", "16"), ("16", "16"), ("1", "16"), ("48", "8"), ("100", "32"), ("128", "64")])
 def test_witness_kernel_geometries(ctx, cache, lpp, monkeypatch):
-    """The witness kernel with no LDS row cache, a small one and large ones, at 16, 32 and 64 lanes per proof: the same
-    trace bytes as the default (32 rows, 16 lanes), which test_pairing_witness_trace checks against the CPU replay."""
+    """The witness kernel with no LDS row cache, one entry, small and large ones, at 8, 16, 32 and 64 lanes per proof
+    (each with its own cache plan): the same trace bytes as the default (32 rows, 16 lanes), which
+    test_pairing_witness_trace checks against the CPU replay."""
     ps, qs = H.random_pairs(5, 9191)
     g1, g2 = H.g1_array(ps), H.g2_array(qs)
     want = ctx.pairing_witness_batch(g1, g2)

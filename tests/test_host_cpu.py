@@ -208,6 +208,28 @@ def test_witness_program_rows_match_circuit_op_totals():
     assert all(names[kinds[i]] == tr.rows[i][0] for i in range(len(kinds)))
 
 
+def test_witness_row_cache_plan_replays():
+    """The witness kernel reads operand rows from a per-proof LDS cache wherever the host-made plan says the row
+    is there.  Replaying the plan: every such read finds its row, no two results of one iteration share an entry,
+    the operations are otherwise those of the circuit replay, and the plan serves most reads at the default size."""
+    import ctypes as C
+    from plonky2_bls12_381_pairing_amd import _lib
+    out = (C.c_uint64 * 4)()
+    reads = None
+    for lpp, rows in ((16, 32), (16, 0), (16, 1), (16, 48), (8, 16), (32, 64), (64, 128), (1, 5)):
+        assert _lib.lib.bls381_debug_witness_cache_plan(lpp, rows, out) == 0
+        assert out[2] == 0, (lpp, rows, list(out))
+        assert out[3] == 141364
+        reads = reads or out[0]
+        assert out[0] == reads  # reads of trace rows do not depend on the plan
+        if rows == 0:
+            assert out[1] == 0
+        if (lpp, rows) == (16, 32):
+            assert out[1] > 0.7 * out[0]
+    assert _lib.lib.bls381_debug_witness_cache_plan(16, 129, out) == -1
+    assert _lib.lib.bls381_debug_witness_cache_plan(5, 32, out) == -1
+
+
 def test_one_hip_runtime_in_either_import_order():
     """This package imported before torch, and torch after it, end up on one libamdhip64 (torch's copy, loaded
     first by the package's loader): two runtimes in one process are what makes torch lose its GPUs."""
