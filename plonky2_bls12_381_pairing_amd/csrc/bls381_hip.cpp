@@ -145,6 +145,7 @@ struct bls381_ctx {
     std::map<std::string, DevProgram> progs;
     uint4* d_consts = nullptr;
     uint4* d_vmconsts = nullptr;
+    uint4* d_trash = nullptr;  // VmArgs::trash
     unsigned long long* d_prof = nullptr;  // set while bls381_debug_profile runs
     const uint4* consts_override = nullptr;  // set while a program runs against a prepared G2 point's table
     DevBuf user_in, user_in2, user_in3, user_in4, user_out, flags, bufA, bufB, bufC, bufD, bufE, bufTmp, zflags, ilist;
@@ -290,6 +291,7 @@ extern "C" int bls381_ctx_create_ex(bls381_ctx** out, int device_id, int K, int 
     fill_vm_constants(vmc);
     if (hipMalloc((void**)&c->d_consts, consts.size() * 4) != hipSuccess ||
         hipMalloc((void**)&c->d_vmconsts, vmc.size() * 4) != hipSuccess ||
+        hipMalloc((void**)&c->d_trash, 64 * 4 * sizeof(uint4)) != hipSuccess ||
         hipMemcpy(c->d_consts, consts.data(), consts.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(c->d_vmconsts, vmc.data(), vmc.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(BLS381_ERR_HIP, "constant upload failed"));
@@ -320,6 +322,7 @@ extern "C" void bls381_ctx_destroy(bls381_ctx* c) {
     c->wit.release();
     if (c->d_consts) (void)hipFree(c->d_consts);
     if (c->d_vmconsts) (void)hipFree(c->d_vmconsts);
+    if (c->d_trash) (void)hipFree(c->d_trash);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->pipe_ev) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -338,7 +341,7 @@ static hipError_t launch_vm_kt(bls381_ctx* c, const DevProgram& p, const uint4* 
     constexpr int GPW = 4 * (64 / K);
     VmArgs a;
     a.blocks = p.d_blocks; a.nblocks = p.nblocks; a.nsteps = (int)p.host.hdrs.size(); a.lds_slots = p.host.n_lds_slots;
-    a.prof = c->d_prof; a.consts = c->consts_override ? c->consts_override : c->d_vmconsts; a.gin = gin; a.gout = gout; a.gtmp = gtmp; a.n = n; a.npad = npad; a.n_dev = c->n_dev_override;
+    a.prof = c->d_prof; a.consts = c->consts_override ? c->consts_override : c->d_vmconsts; a.gin = gin; a.gout = gout; a.gtmp = gtmp; a.n = n; a.npad = npad; a.n_dev = c->n_dev_override; a.trash = c->d_trash;
     // the spill array's 8-byte tails follow its 48-byte parts
     a.gtmp_tail = reinterpret_cast<uint2*>(gtmp + (size_t)std::max(1, p.host.n_tmp_slots) * 3 * npad);
     size_t lds = vm_lds_bytes(p.host.n_lds_slots, K);

@@ -623,23 +623,28 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
     std::vector<int> free_tmp;
     int n_tmp = 0;
 
-    auto emit_copy_steps = [&](std::vector<CopyOp>& ops) {
-        for (size_t base = 0; base < ops.size(); base += K) {
-            StepHdr h{ST_COPY, 0};
-            P.hdrs.push_back(h);
-            for (int r = 0; r < K; r++) {
-                OpDesc d; std::memset(&d, 0, sizeof d);
-                if (base + r < ops.size()) {
-                    const CopyOp& c = ops[base + r];
-                    d.hdr = 1u | ((uint32_t)c.kind << 8);
-                    d.w[0] = (uint16_t)c.dst; d.w[1] = (uint16_t)c.src;
-                    P.n_copy++;
+    // A copy step holds copies of one kind, named in its header: the kernel branches on the kind once for all lanes.
+    auto emit_copy_steps = [&](std::vector<CopyOp>& all) {
+        for (uint32_t kind = 0; kind <= CK_OUT; kind++) {
+            std::vector<CopyOp> ops;
+            for (const CopyOp& c : all) if ((uint32_t)c.kind == kind) ops.push_back(c);
+            for (size_t base = 0; base < ops.size(); base += K) {
+                StepHdr h{ST_COPY, kind};
+                P.hdrs.push_back(h);
+                for (int r = 0; r < K; r++) {
+                    OpDesc d; std::memset(&d, 0, sizeof d);
+                    if (base + r < ops.size()) {
+                        const CopyOp& c = ops[base + r];
+                        d.hdr = 1u | ((uint32_t)c.kind << 8);
+                        d.w[0] = (uint16_t)c.dst; d.w[1] = (uint16_t)c.src;
+                        P.n_copy++;
+                    }
+                    P.descs.push_back(d);
                 }
-                P.descs.push_back(d);
+                P.n_copy_steps++;
             }
-            P.n_copy_steps++;
         }
-        ops.clear();
+        all.clear();
     };
 
     // Copies ride on compute steps where they can ("piggyback"): a lane of a multiplier or sum step
@@ -759,12 +764,25 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         emit_copy_steps(spills_a);
         emit_copy_steps(fills);
         emit_copy_steps(spills_b);
-        // 4. the step itself
+        // 4. the step itself (a step of copies: one step per kind of copy)
+        std::vector<std::vector<int>> parts;
+        if (st.cls == OC_COPY) {
+            for (NodeKind nk : {NK_LOADIN, NK_LOADC, NK_STOREOUT}) {
+                std::vector<int> part;
+                for (int op : st.ops) if (N[op].kind == nk) part.push_back(op);
+                if (!part.empty()) parts.push_back(part);
+            }
+        } else {
+            parts.push_back(st.ops);
+        }
+        for (const std::vector<int>& step_ops : parts) {
         StepHdr h; h.max_terms = 0;
+        if (st.cls == OC_COPY)
+            h.max_terms = N[step_ops[0]].kind == NK_LOADIN ? CK_IN : (N[step_ops[0]].kind == NK_LOADC ? CK_CONST : CK_OUT);
         int step_rounds = 0;
         bool any_dot2 = false;
         int mul_width = 1;
-        for (int op : st.ops) {
+        for (int op : step_ops) {
             any_dot2 |= (N[op].kind == NK_DOT2);
             if (is_mul(N[op])) mul_width = std::max(mul_width, mul_shape(N[op]).width);
         }
@@ -787,8 +805,8 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
                     P.n_piggy_spill++;
                 }
             }
-            if (r < (int)st.ops.size()) {
-                int op = st.ops[r];
+            if (r < (int)step_ops.size()) {
+                int op = step_ops[r];
                 const Node& nd = N[op];
                 d.hdr = 1u;
                 switch (nd.kind) {
@@ -865,6 +883,11 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         if (st.cls == OC_LIN) h.max_terms |= (uint32_t)step_rounds << 8;  // carry sweep / reduction wanted by some op
         if (!cur_spills.empty()) h.max_terms |= 1u << 17;
         P.hdrs.push_back(h);
+        if (st.cls == OC_COPY) P.n_copy_steps++;
+        if (st.cls == OC_FMUL && mul_width > 1) P.n_wide_mul_steps++;
+        if (st.cls == OC_FMUL && any_dot2) P.n_dot2_steps++;
+        else if (st.cls == OC_FMUL) P.n_fmul_steps++;
+        }
         prev_open = st.cls != OC_COPY;
         prev_idx = P.hdrs.size() - 1;
         prev_results.clear();
@@ -872,12 +895,8 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         prev_nfill = 0; prev_nspill = (int)cur_spills.size();
         prev_spilled.clear();
         for (auto& cs : cur_spills) prev_spilled.insert(cs.second);
-        if (st.cls == OC_FMUL && mul_width > 1) P.n_wide_mul_steps++;
-        if (st.cls == OC_FMUL && any_dot2) P.n_dot2_steps++;
-        else if (st.cls == OC_FMUL) P.n_fmul_steps++;
-        else if (st.cls == OC_LIN) P.n_lin_steps++;
+        if (st.cls == OC_LIN) P.n_lin_steps++;
         else if (st.cls == OC_DOTN) P.n_dotn_steps++;
-        else P.n_copy_steps++;
         // values produced but never read (cannot happen after DCE) would leak a slot; guard anyway
         for (int op : st.ops)
             if (N[op].kind != NK_STOREOUT && use_steps[op].empty()) {

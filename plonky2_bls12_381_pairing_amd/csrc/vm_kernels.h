@@ -31,6 +31,7 @@ struct VmArgs {
     const int* n_dev;  // when set: a count in device memory that further limits n (workgroups beyond it exit at once)
     int npad;  // element stride of the global slot arrays
     unsigned long long* prof;  // TAG_PROFILE only: [0..16) cycles per step kind, [16..32) step counts
+    uint4* trash;  // 64 x 4 uint4: where the lanes of a copy step that have no copy of their own store
 };
 
 enum { VM_THREADS = 256 };
@@ -364,61 +365,74 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             }
             lds_store(dst, r);
         } else {  // ST_COPY: every lane reads before any lane writes
-            const u32 kind = (dx >> 5) & 7u;
-            const u32 src = dy;
+            // No lane-dependent branch in here: the copy kind is the step's (uniform), and a lane without a copy of
+            // its own runs the same loads and stores on harmless addresses (the constant table, the ZERO and TRASH
+            // slots, the trash array).  A divergent branch anywhere in the step dispatch would have the compiler
+            // linearise the whole dispatch into a chain of flag tests that every step then walks.
+            const u32 kind = max_terms;  // (copy steps keep their CopyKind in the term-count field)
+            const int trash_slot = A.lds_slots - 1, zero_slot = A.lds_slots - 2;
+            // Element offsets into the slot arrays (below 2^32 uint4: at most 1,024 slots of 3 x 65,536), computed for
+            // every lane and passed through an empty asm so that choosing between them stays a select (the compiler
+            // turns a select whose operands take work to compute back into a branch).
+            const u32 src = dy & 0xffffu;
+            u32 off_src = src * 3u * (u32)A.npad + (u32)e, off_src_tail = src * (u32)A.npad + (u32)e;
+            u32 off_dst = dst * 3u * (u32)A.npad + (u32)e, off_dst_tail = dst * (u32)A.npad + (u32)e;
+            u32 off_trash = (u32)lane * 4u, off_const = src * 4u;
+            asm volatile("" : "+v"(off_src), "+v"(off_src_tail), "+v"(off_dst), "+v"(off_dst_tail), "+v"(off_trash), "+v"(off_const));
             // A fill may read what an earlier spill of this wave wrote (spills themselves are not
             // waited for): drain the wave's stores first.
-            if (__builtin_amdgcn_ballot_w64(on && kind == CK_FILL) != 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (kind == CK_FILL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             u32 v[D28];
-#pragma unroll
-            for (int i = 0; i < D28; i++) v[i] = 0;
-            if (on) {
-                if (kind == CK_IN) {
-                    const uint4* p = A.gin + ((size_t)src * 3) * A.npad + e;
-                    uint4 v0 = p[0], v1 = p[A.npad], v2 = p[2 * (size_t)A.npad];
-                    u32 l[12];
-                    unpack3(v0, v1, v2, l);
-                    unpack28(l, v);
-                } else if (kind == CK_FILL) {
-                    const uint4* p = A.gtmp + ((size_t)src * 3) * A.npad + e;
-                    uint4 v0 = p[0], v1 = p[A.npad], v2 = p[2 * (size_t)A.npad];
-                    uint2 t = A.gtmp_tail[(size_t)src * A.npad + e];
-                    unpack3(v0, v1, v2, v);
-                    v[12] = t.x; v[13] = t.y;
-                } else if (kind == CK_CONST) {
-                    const uint4* p = A.consts + (size_t)src * 4;
-                    uint4 v0 = p[0], v1 = p[1], v2 = p[2];
-                    global_u32x2_ptr pt = (global_u32x2_ptr)(p + 3);
-                    asm volatile("" : "+v"(pt));
-                    const u32x2_t v3 = *pt;
-                    unpack3(v0, v1, v2, v);
-                    v[12] = v3.x; v[13] = v3.y;
-                } else {
-                    lds_load(src, v);
-                }
+            if (kind == CK_IN) {  // (idle lanes read the first element's slot 0: always there)
+                const uint4* p = A.gin + (on ? off_src : 0u);
+                uint4 v0 = p[0], v1 = p[A.npad], v2 = p[2 * (size_t)A.npad];
+                u32 l[12];
+                unpack3(v0, v1, v2, l);
+                unpack28(l, v);
+            } else if (kind == CK_FILL) {
+                const uint4* p = A.gtmp + (on ? off_src : 0u);
+                const uint2* pt = A.gtmp_tail + (on ? off_src_tail : 0u);
+                uint4 v0 = p[0], v1 = p[A.npad], v2 = p[2 * (size_t)A.npad];
+                uint2 t = *pt;
+                unpack3(v0, v1, v2, v);
+                v[12] = t.x; v[13] = t.y;
+            } else if (kind == CK_CONST) {
+                const uint4* p = A.consts + (on ? off_const : 0u);
+                uint4 v0 = p[0], v1 = p[1], v2 = p[2];
+                global_u32x2_ptr pt = (global_u32x2_ptr)(p + 3);
+                asm volatile("" : "+v"(pt));
+                const u32x2_t v3 = *pt;
+                unpack3(v0, v1, v2, v);
+                v[12] = v3.x; v[13] = v3.y;
+            } else {
+                lds_load(on ? (int)src : zero_slot, v);
             }
             // Every path consumes the loaded registers here.  Otherwise the compiler must assume a
             // load may still be in flight when other steps reuse those registers and guards them
             // with waits that also stall on unrelated stores and descriptor prefetches.
             asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
                               "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]));
-            if (on) {
-                if (kind <= CK_CONST) {
-                    lds_store(dst, v);
-                } else if (kind == CK_SPILL) {
-                    uint4* p = A.gtmp + ((size_t)dst * 3) * A.npad + e;
+            if (kind <= CK_CONST) {
+                lds_store(on ? (int)dst : trash_slot, v);
+            } else {
+                // idle lanes store four consecutive uint4 of the trash array, the others three slot-array chunks
+                // (and, spilling, the tail)
+                u32 st = on ? (u32)A.npad : 1u;
+                if (kind == CK_SPILL) {
+                    uint4* p = (on ? A.gtmp : A.trash) + (on ? off_dst : off_trash);
+                    uint2* pt = on ? A.gtmp_tail + off_dst_tail : reinterpret_cast<uint2*>(A.trash + off_trash + 3);
                     p[0] = make_uint4(v[0], v[1], v[2], v[3]);
-                    p[A.npad] = make_uint4(v[4], v[5], v[6], v[7]);
-                    p[2 * (size_t)A.npad] = make_uint4(v[8], v[9], v[10], v[11]);
-                    A.gtmp_tail[(size_t)dst * A.npad + e] = make_uint2(v[12], v[13]);
+                    p[st] = make_uint4(v[4], v[5], v[6], v[7]);
+                    p[2 * (size_t)st] = make_uint4(v[8], v[9], v[10], v[11]);
+                    *pt = make_uint2(v[12], v[13]);
                 } else {  // CK_OUT: below 2p -> canonical, 12 x u32
                     canon28(v);
                     u32 l[12];
                     pack28(v, l);
-                    uint4* p = A.gout + ((size_t)dst * 3) * A.npad + e;
+                    uint4* p = (on ? A.gout : A.trash) + (on ? off_dst : off_trash);
                     p[0] = make_uint4(l[0], l[1], l[2], l[3]);
-                    p[A.npad] = make_uint4(l[4], l[5], l[6], l[7]);
-                    p[2 * (size_t)A.npad] = make_uint4(l[8], l[9], l[10], l[11]);
+                    p[st] = make_uint4(l[4], l[5], l[6], l[7]);
+                    p[2 * (size_t)st] = make_uint4(l[8], l[9], l[10], l[11]);
                 }
             }
         }

@@ -288,6 +288,7 @@ def run_program(prog, gin, strict=True, extra_consts=()):
                 lin(nt, (d[0] >> 24) & 0xf, w[1:1 + (mt & 0xff)], w[0])
             else:
                 kind = (d[0] >> 8) & 0xff
+                assert kind == (mt & 0xff)  # the kernel takes the kind of a copy step from the step's header
                 if kind == CK_IN:
                     assert gin[w[1]] < 1 << 384
                     writes.append(("lds", w[0], to_digits(gin[w[1]])))
