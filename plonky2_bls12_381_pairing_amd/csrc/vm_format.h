@@ -83,16 +83,16 @@ enum { LIN_MAX_TERMS = 7, MUL_MAX_TERMS = 3, DOTN_MAX_PAIRS = 8, LIN_MAX_COEF = 
 //   w[0] bit 0 active, bit 1 second product, bits 3..4 and 2 StepType (bit 2 = its bit 2),
 //        bits 5..7 the step's largest term count (sums: terms of an op; multiplier steps: terms of an operand;
 //        ST_DOTN: products of an op, minus one; copy steps: the CopyKind), bits 8..9 sweep / reduce flags of the step,
-//        bit 10 the step reads w[3], bit 11 the step reads w[4], sums: bits 12..15 the shifted zero B (signed),
-//        bits 16..31 destination slot
-//        (multiplier and sum steps: destination in bits 16..22, bit 23 some lane of the step
-//        carries a fill, bit 24 some lane carries a spill)
+//        bit 10 the step reads w[3], bit 11 the step reads w[4] (informative: the kernel fetches w[3] always and w[4]
+//        where a sum has seven terms), sums: bits 12..15 the shifted zero B (signed),
+//        multiplier and sum steps: destination slot in bits 16..22, bit 23 some lane of the step
+//        carries a fill, bit 24 some lane carries a spill; copy steps: bits 16..31 zero
 //   multiplier steps: w[1 + t], t = 0..2: term t of the operands a, b, c, d in bytes 0..3: LDS slot in bits 0..6,
 //        negate in bit 7
 //   ST_DOTN: w[1 + t / 2], half t % 2: product t: first factor's slot in bits 0..6, second factor's in bits 8..14,
 //        negate in bit 15
 //   sum steps: w[1 + i / 2], half i % 2: term i: LDS slot in bits 0..6, coefficient in bits 7..14
-//   copy steps: w[1] = source slot
+//   copy steps: w[1] = source slot, w[2] = destination slot
 //   w[5] carried copies: bits 0..6 fill LDS slot, 7..8 CopyKind, 9..18 source slot, 19 valid;
 //        bits 20..26 spill LDS slot, 27 valid; the spill-array slot sits in w[0] bits 25..31
 struct PackedDesc {
@@ -101,12 +101,13 @@ struct PackedDesc {
 inline PackedDesc pack_desc(const StepHdr& h, const OpDesc& d) {
     PackedDesc p{{0, 0, 0, 0, 0, 0, 0, 0}};
     const uint32_t nterms_step = h.max_terms & 0xffu, flags = (h.max_terms >> 8) & 3u;
-    p.w[0] = (d.hdr & 3u) | ((h.type & 3u) << 3) | (h.type & 4u) | ((h.type == ST_DOTN ? nterms_step - 1 : nterms_step) << 5) | (flags << 8) |
-             ((uint32_t)d.w[0] << 16);
+    p.w[0] = (d.hdr & 3u) | ((h.type & 3u) << 3) | (h.type & 4u) | ((h.type == ST_DOTN ? nterms_step - 1 : nterms_step) << 5) | (flags << 8);
     if (h.type == ST_COPY) {
         p.w[0] |= ((d.hdr >> 8) & 7u) << 5;  // (the term-count field is the copy kind here)
         p.w[1] = d.w[1];
+        p.w[2] = d.w[0];  // (a copy's destination may be any slot of a global array: a field of its own)
     } else {
+        p.w[0] |= (uint32_t)d.w[0] << 16;
         // which of the words beyond w[2] the step's lanes have to fetch
         if (h.type == ST_LIN || h.type == ST_DOTN ? nterms_step > 4 : nterms_step > 2) p.w[0] |= 1u << 10;
         if ((h.type == ST_LIN || h.type == ST_DOTN) && nterms_step > 6) p.w[0] |= 1u << 11;

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                                      : (type == ST_LIN ? (flags & 2u ? 9 : (flags ? 2 : 1)) : (type == ST_DOTN ? 11 : (max_terms > 1 ? 10 : (int)type)));
         }
         const bool on = lane_on && (dx & 1u);
-        const u32 dst = type == ST_COPY ? dx >> 16 : (dx >> 16) & 0x7fu;
+        const u32 dst = type == ST_COPY ? dz & 0xffffu : (dx >> 16) & 0x7fu;
 
         // Copies carried by a multiplier or sum step.  Fill: the loads are issued now and land in LDS
         // after the step's results, their latency behind the step's arithmetic.  Spill: LDS slot ->
@@ -151,59 +151,57 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
         u32 pf[D28];  // deliberately not initialised: a merge with constants would make the compiler copy
                       // the loaded registers, and so wait for the loads, right where they are issued
         u32 dw = 0;   // the descriptor word of the carried copies, fetched only by steps that carry any
-        const bool carries = type != ST_COPY && (hx & (3u << 23));  // (a copy step's destination field extends over these bits)
-        // Descriptor words beyond the first three are fetched here, before the step issues any load from global
-        // memory: the block's registers came from global loads themselves, and a wait for them placed after the
-        // carried fills' loads would wait for those too.
-        u32 d3 = 0, d4 = 0;  // sums: terms 4..6; multiplier steps: the operands' third terms
-        if (hx & (1u << 10)) d3 = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur.w);
-        if (hx & (1u << 11)) d4 = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur_hi.x);
-        if (carries) {
-            dw = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur_hi.y);
-            asm volatile("" : "+v"(dw));  // nothing derived from dw is computed (and waited for) by steps that carry nothing
-        }
-        if (carries && (hx & (1u << 23))) {
-            // a fill may read what a spill of an earlier step wrote: drain the wave's stores first
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane_on && (dw & (1u << 19))) {
-                const u32 fk = (dw >> 7) & 3u, src = (dw >> 9) & 0x3ffu;
-                if (fk == CK_CONST) {
-                    const uint4* p = A.consts + (size_t)src * 4;
-                    uint4 v0 = p[0], v1 = p[1], v2 = p[2];
-                    // 8 bytes, not 16: registers a load writes but nothing reads get reused at once, and
-                    // the reuse then has to wait for the load
-                    // (a pointer known to be global memory: laundered as a generic pointer the load would be a flat
-                    // load, which counts as LDS traffic too and makes every later wait a wait for everything)
-                    global_u32x2_ptr pt = (global_u32x2_ptr)(p + 3);
-                    asm volatile("" : "+v"(pt));  // keeps the compiler from widening the load again
-                    const u32x2_t v3 = *pt;
-                    unpack3(v0, v1, v2, pf);
-                    pf[12] = v3.x; pf[13] = v3.y;
-                } else {
-                    const uint4* p = (fk == CK_IN ? A.gin : A.gtmp) + ((size_t)src * 3) * A.npad + e;
-                    uint4 v0 = p[0], v1 = p[A.npad], v2 = p[2 * (size_t)A.npad];
-                    unpack3(v0, v1, v2, pf);
-                    if (fk == CK_FILL) {
-                        uint2 t = A.gtmp_tail[(size_t)src * A.npad + e];
-                        pf[12] = t.x; pf[13] = t.y;
-                    }
-                }
-            }
-        }
-
+        const bool carries = hx & (3u << 23);  // (one test for the steps that carry nothing: most of them)
+        // The operands' third terms / a sum's terms 4 and 5 are fetched by every step (one instruction, against a test
+        // and a branch to skip it), and here, before the step issues any load from global memory: the block's
+        // registers came from global loads themselves, and a wait for them placed after the carried fills' loads
+        // would wait for those too.  (A sum's seventh term is fetched by the sums that have one.)
+        const u32 d3 = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur.w);
         // (the spilled value's registers stay reserved until the step ends, see there: gfx9 has one counter for
         // loads and stores, and reusing a register a store still reads from means waiting for that store, which,
         // the counter being in order, means waiting for the fills' loads issued before it)
         u32 sv[D28];
-        if (carries && (hx & (1u << 24))) {
-            if (lane_on && (dw & (1u << 27))) {
-                lds_load((dw >> 20) & 0x7fu, sv);
-                const u32 t = dx >> 25;
-                uint4* p = A.gtmp + ((size_t)t * 3) * A.npad + e;
-                p[0] = make_uint4(sv[0], sv[1], sv[2], sv[3]);
-                p[A.npad] = make_uint4(sv[4], sv[5], sv[6], sv[7]);
-                p[2 * (size_t)A.npad] = make_uint4(sv[8], sv[9], sv[10], sv[11]);
-                A.gtmp_tail[(size_t)t * A.npad + e] = make_uint2(sv[12], sv[13]);
+        if (carries) {
+            dw = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur_hi.y);
+            asm volatile("" : "+v"(dw));  // nothing derived from dw is computed (and waited for) by steps that carry nothing
+            if (hx & (1u << 23)) {
+                // a fill may read what a spill of an earlier step wrote: drain the wave's stores first
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane_on && (dw & (1u << 19))) {
+                    const u32 fk = (dw >> 7) & 3u, src = (dw >> 9) & 0x3ffu;
+                    if (fk == CK_CONST) {
+                        const uint4* p = A.consts + (size_t)src * 4;
+                        uint4 v0 = p[0], v1 = p[1], v2 = p[2];
+                        // 8 bytes, not 16: registers a load writes but nothing reads get reused at once, and
+                        // the reuse then has to wait for the load
+                        // (a pointer known to be global memory: laundered as a generic pointer the load would be a flat
+                        // load, which counts as LDS traffic too and makes every later wait a wait for everything)
+                        global_u32x2_ptr pt = (global_u32x2_ptr)(p + 3);
+                        asm volatile("" : "+v"(pt));  // keeps the compiler from widening the load again
+                        const u32x2_t v3 = *pt;
+                        unpack3(v0, v1, v2, pf);
+                        pf[12] = v3.x; pf[13] = v3.y;
+                    } else {
+                        const uint4* p = (fk == CK_IN ? A.gin : A.gtmp) + ((size_t)src * 3) * A.npad + e;
+                        uint4 v0 = p[0], v1 = p[A.npad], v2 = p[2 * (size_t)A.npad];
+                        unpack3(v0, v1, v2, pf);
+                        if (fk == CK_FILL) {
+                            uint2 t = A.gtmp_tail[(size_t)src * A.npad + e];
+                            pf[12] = t.x; pf[13] = t.y;
+                        }
+                    }
+                }
+            }
+            if (hx & (1u << 24)) {
+                if (lane_on && (dw & (1u << 27))) {
+                    lds_load((dw >> 20) & 0x7fu, sv);
+                    const u32 t = dx >> 25;
+                    uint4* p = A.gtmp + ((size_t)t * 3) * A.npad + e;
+                    p[0] = make_uint4(sv[0], sv[1], sv[2], sv[3]);
+                    p[A.npad] = make_uint4(sv[4], sv[5], sv[6], sv[7]);
+                    p[2 * (size_t)A.npad] = make_uint4(sv[8], sv[9], sv[10], sv[11]);
+                    A.gtmp_tail[(size_t)t * A.npad + e] = make_uint2(sv[12], sv[13]);
+                }
             }
         }
         // Multiplier and sum steps are branch-free: idle lanes read the ZERO slot and store to TRASH.
@@ -217,6 +215,7 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             u64 acc[D28];
             const int B = (int)(dx << 16) >> 28;  // bits 12..15, signed
             const u64 z0 = (u32)(B << 28), zm = (u32)((B << 28) - B), zt = (u32)(-B);
+            u32 d4 = 0;  // the seventh term
             auto TERM = [&](int i) -> u32 { return ((i < 2 ? dy : (i < 4 ? dz : (i < 6 ? d3 : d4))) >> ((i & 1) * 16)) & 0x7fffu; };
             auto terms = [&](auto first_tag, auto count_tag) {
                 constexpr int T0 = decltype(first_tag)::value, N = decltype(count_tag)::value;
@@ -245,6 +244,7 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                     else terms(BLS381_IC(0), BLS381_IC(4));
                 }
             } else {
+                if (max_terms > 6) d4 = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur_hi.x);
                 terms(BLS381_IC(0), BLS381_IC(4));
                 if (max_terms == 5) terms(BLS381_IC(4), BLS381_IC(1));
                 else if (max_terms == 6) terms(BLS381_IC(4), BLS381_IC(2));
@@ -263,6 +263,8 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             // product t is multiplied.  Ops with fewer products than the step's largest count are padded with
             // ZERO * ZERO.  The columns hold up to 8 x 14 products of normalised digits plus the reduction's.
             const int npairs = (int)max_terms + 1;  // uniform, 3..8
+            u32 d4 = 0;
+            if (npairs > 6) d4 = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur_hi.x);
             auto PAIR = [&](int t) -> u32 { return ((t < 2 ? dy : (t < 4 ? dz : (t < 6 ? d3 : d4))) >> ((t & 1) * 16)) & 0xffffu; };
             int64_t col[2 * D28];
 #pragma unroll
