@@ -80,7 +80,7 @@ enum { LIN_MAX_TERMS = 7, MUL_MAX_TERMS = 3, DOTN_MAX_PAIRS = 8, LIN_MAX_COEF = 
 // so two 16-byte loads per lane fetch a whole block for a wave and the lanes then pick their
 // descriptors out of each other's registers.  The step-wide fields are replicated into every
 // descriptor of the step:
-//   w[0] bit 0 active, bit 1 second product, bits 3..4 and 2 StepType (bit 2 = its bit 2),
+//   w[0] bit 0 active, bit 1 second product, bits 2..4 StepType,
 //        bits 5..7 the step's largest term count (sums: terms of an op; multiplier steps: terms of an operand;
 //        ST_DOTN: products of an op, minus one; copy steps: the CopyKind), bits 8..9 sweep / reduce flags of the step,
 //        bit 10 the step reads w[3], bit 11 the step reads w[4] (informative: the kernel fetches w[3] always and w[4]
@@ -101,7 +101,7 @@ struct PackedDesc {
 inline PackedDesc pack_desc(const StepHdr& h, const OpDesc& d) {
     PackedDesc p{{0, 0, 0, 0, 0, 0, 0, 0}};
     const uint32_t nterms_step = h.max_terms & 0xffu, flags = (h.max_terms >> 8) & 3u;
-    p.w[0] = (d.hdr & 3u) | ((h.type & 3u) << 3) | (h.type & 4u) | ((h.type == ST_DOTN ? nterms_step - 1 : nterms_step) << 5) | (flags << 8);
+    p.w[0] = (d.hdr & 3u) | ((h.type & 7u) << 2) | ((h.type == ST_DOTN ? nterms_step - 1 : nterms_step) << 5) | (flags << 8);
     if (h.type == ST_COPY) {
         p.w[0] |= ((d.hdr >> 8) & 7u) << 5;  // (the term-count field is the copy kind here)
         p.w[1] = d.w[1];

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
         }
         const int self = (j * K + role) * 4;
         const u32 hx = (u32)__builtin_amdgcn_readfirstlane((int)dx);  // step-wide fields
-        const u32 type = ((hx >> 3) & 3u) | (hx & 4u), max_terms = (hx >> 5) & 7u, flags = (hx >> 8) & 3u;
+        const u32 type = (hx >> 2) & 7u, max_terms = (hx >> 5) & 7u, flags = (hx >> 8) & 3u;
         if (TAG == TAG_PROFILE && tid == 0 && blockIdx.x == 0) {
             const long long now = clock64();
             if (k_prev >= 0) {
@@ -438,10 +438,11 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                 }
             }
         }
-        if (carries && (hx & (1u << 24)))
+        if (carries) {
+        if (hx & (1u << 24))
             asm volatile("" : : "v"(sv[0]), "v"(sv[1]), "v"(sv[2]), "v"(sv[3]), "v"(sv[4]), "v"(sv[5]), "v"(sv[6]), "v"(sv[7]),
                                 "v"(sv[8]), "v"(sv[9]), "v"(sv[10]), "v"(sv[11]), "v"(sv[12]), "v"(sv[13]));
-        if (carries && (hx & (1u << 23))) {
+        if (hx & (1u << 23)) {
             // every path consumes the loaded registers here (see the copy step)
             asm volatile("" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(pf[3]), "+v"(pf[4]), "+v"(pf[5]), "+v"(pf[6]),
                               "+v"(pf[7]), "+v"(pf[8]), "+v"(pf[9]), "+v"(pf[10]), "+v"(pf[11]), "+v"(pf[12]), "+v"(pf[13]));
@@ -454,6 +455,7 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                 }
                 lds_store(dw & 0x7fu, pf);
             }
+        }
         }
       }
       cur = nxt; cur_hi = nxt_hi;
