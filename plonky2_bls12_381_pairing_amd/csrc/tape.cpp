@@ -344,6 +344,7 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
     // or reduction there spares each consumer (and their consumers) its own.
     const int VB_EAGER = env_int("BLS381_VB_EAGER", 400), DB_EAGER = env_int("BLS381_DB_EAGER", 3);
     const bool use_bias = env_int("BLS381_LIN_BIAS", 1) != 0;
+    const int REDUCE_SIBLINGS = env_int("BLS381_REDUCE_SIBLINGS", 12), REDUCE_SIBLING_RATIO = env_int("BLS381_REDUCE_SIBLING_RATIO", 4);
     struct SumBound { long v; int lo, hi, mag; };
     auto sum_bound = [&](const std::vector<Term>& terms) {
         SumBound b{0, 0, 0, 0};
@@ -361,7 +362,22 @@ Program schedule(const Dag& dag, int K, int lds_slots, const std::string& name) 
         for (int i = 0; i < n;) {
             const Node& nd = N[i];
             int redo = -1;  // node whose flags changed
-            auto treated = [&](int x, std::vector<char>& flag, int& counter) { treat(x, flag, counter); redo = x; };
+            // A reduction is a flag of the whole step: every sum that shares the step pays for it.  So a sum that must
+            // be reduced takes its neighbours in node order along (the components of one tower value, which the
+            // scheduler puts into the same steps) when they have grown as well: their next reductions then fall
+            // together too, instead of one or two in every other step.
+            auto treated = [&](int x, std::vector<char>& flag, int& counter) {
+                treat(x, flag, counter);
+                redo = x;
+                if (&flag == &lin_reduce && N[x].kind == NK_LIN && REDUCE_SIBLINGS > 0) {
+                    for (int y = std::max(0, x - REDUCE_SIBLINGS); y < std::min(i, x + REDUCE_SIBLINGS + 1); y++) {
+                        if (y == x || N[y].kind != NK_LIN || lin_reduce[y] || succ[y].size() < 2) continue;
+                        if ((long)vb[y] * REDUCE_SIBLING_RATIO < vb[x]) continue;
+                        lin_reduce[y] = 1; counter++;
+                        redo = std::min(redo, y);
+                    }
+                }
+            };
             switch (nd.kind) {
                 case NK_LOADIN: vb[i] = 10; dlo[i] = 0; dhi[i] = 1; break;  // any 384-bit pattern is below 10p
                 case NK_LOADC: vb[i] = 1; dlo[i] = 0; dhi[i] = 1; break;
