@@ -526,6 +526,26 @@ def test_other_lane_group_geometries(lanes, slots):
         prep.close()
 
 
+@pytest.mark.parametrize("knob,value", [("BLS381_REDUCE_SIBLINGS", "0"), ("BLS381_NO_PIGGYBACK", "1"), ("BLS381_WINDOW", "200"),
+                                        ("BLS381_ABSORB_TERMS", "1"), ("BLS381_VB_EAGER", "50")])
+def test_other_schedules_give_the_same_values(ctx, knob, value, monkeypatch):
+    """The scheduler's policies (which sums are reduced together, copies riding on compute steps or in steps of their
+    own, the look-ahead window, sums folded into multiplier operands or not, eager reductions) change the step programs,
+    never the values: a context built under another policy returns the default context's bytes for pairings, Miller
+    values and final exponentiations of arbitrary input."""
+    import plonky2_bls12_381_pairing_amd as B
+    ps, qs = H.random_pairs(37, 4242)
+    g1, g2 = H.g1_array(ps), H.g2_array(qs)
+    want, want_ml = ctx.pairing_batch(g1, g2), ctx.miller_loop_batch(g1, g2)
+    x = H.fq12_array(H.random_fq12(5, 77))
+    want_fe = ctx.final_exponentiation_batch(x)
+    monkeypatch.setenv(knob, value)
+    with B.Context(0) as c:
+        assert np.array_equal(c.pairing_batch(g1, g2), want)
+        assert np.array_equal(c.miller_loop_batch(g1, g2), want_ml)
+        assert np.array_equal(c.final_exponentiation_batch(x), want_fe)
+
+
 def test_lazy_product_programs(monkeypatch):
     """The 6-lane programs built from n-product operations (schoolbook Fq6 products and line products, one reduction
     per component) give the same pairings, Miller values and Fq12 products, bit for bit, as the same width with
