@@ -92,17 +92,31 @@ struct DevProgram {
     Program host;
     uint4* d_blocks = nullptr;  // packed descriptors, see PackedDesc
     int nblocks = 0;
+    int nsteps = 0;  // device steps (a short sum step may share the descriptors of the step before it)
 };
 
 // 64 packed descriptors per block, as two planes of 64 x 16 bytes (words 0..3, then words 4..7): step j of the
 // block, lane-in-group r at index j * K + r of each plane
-static std::vector<uint32_t> pack_blocks(const Program& p) {
+static std::vector<uint32_t> pack_blocks(const Program& p, int& nsteps_dev, bool may_pair) {
     const int K = p.K, spb = 64 / K, nsteps = (int)p.hdrs.size();
-    const int nblocks = (nsteps + spb - 1) / spb;
+    // device steps: a program step, or two where the second is a short sum that can ride in the first's descriptors
+    const bool pair_steps = may_pair && getenv("BLS381_NO_STEP_PAIRS") == nullptr;
+    std::vector<std::vector<PackedDesc>> steps;
+    for (int s = 0; s < nsteps; s++) {
+        std::vector<PackedDesc> row(K);
+        for (int r = 0; r < K; r++) row[r] = pack_desc(p.hdrs[s], p.descs[(size_t)s * K + r]);
+        if (pair_steps && s + 1 < nsteps && can_take_second_sum(p.hdrs[s], p.hdrs[s + 1])) {
+            for (int r = 0; r < K; r++) pack_second_sum(row[r], p.hdrs[s + 1], p.descs[(size_t)(s + 1) * K + r]);
+            s++;
+        }
+        steps.push_back(row);
+    }
+    nsteps_dev = (int)steps.size();
+    const int nblocks = (nsteps_dev + spb - 1) / spb;
     std::vector<uint32_t> out((size_t)std::max(1, nblocks) * 512, 0u);
-    for (int s = 0; s < nsteps; s++)
+    for (int s = 0; s < nsteps_dev; s++)
         for (int r = 0; r < K; r++) {
-            const PackedDesc d = pack_desc(p.hdrs[s], p.descs[(size_t)s * K + r]);
+            const PackedDesc& d = steps[s][r];
             uint32_t* blk = &out[(size_t)(s / spb) * 512];
             const int at = (s % spb) * K + r;
             for (int w = 0; w < 4; w++) { blk[at * 4 + w] = d.w[w]; blk[256 + at * 4 + w] = d.w[4 + w]; }
@@ -248,7 +262,8 @@ static int upload_program(bls381_ctx* c, const std::string& which) {
         return fail(BLS381_ERR_INVALID, std::string("program ") + which + ": " + e.what());
     }
     if (dp.host.n_lds_slots > MAX_LDS_SLOTS) return fail(BLS381_ERR_INVALID, "more LDS slots than a descriptor can address");
-    std::vector<uint32_t> blocks = pack_blocks(dp.host);
+    // (the single-kind timing programs keep one operation per step: that is what they measure)
+    std::vector<uint32_t> blocks = pack_blocks(dp.host, dp.nsteps, which.rfind("t_", 0) != 0);
     dp.nblocks = (int)(blocks.size() / 512);
     HIPCHK(hipMalloc((void**)&dp.d_blocks, blocks.size() * 4));
     hipError_t e = hipMemcpy(dp.d_blocks, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice);
@@ -340,7 +355,7 @@ static hipError_t launch_vm_kt(bls381_ctx* c, const DevProgram& p, const uint4* 
                                int npad) {
     constexpr int GPW = 4 * (64 / K);
     VmArgs a;
-    a.blocks = p.d_blocks; a.nblocks = p.nblocks; a.nsteps = (int)p.host.hdrs.size(); a.lds_slots = p.host.n_lds_slots;
+    a.blocks = p.d_blocks; a.nblocks = p.nblocks; a.nsteps = p.nsteps; a.lds_slots = p.host.n_lds_slots;
     a.prof = c->d_prof; a.consts = c->consts_override ? c->consts_override : c->d_vmconsts; a.gin = gin; a.gout = gout; a.gtmp = gtmp; a.n = n; a.npad = npad; a.n_dev = c->n_dev_override; a.trash = c->d_trash;
     // the spill array's 8-byte tails follow its 48-byte parts
     a.gtmp_tail = reinterpret_cast<uint2*>(gtmp + (size_t)std::max(1, p.host.n_tmp_slots) * 3 * npad);

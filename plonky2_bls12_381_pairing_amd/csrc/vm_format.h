@@ -83,8 +83,8 @@ enum { LIN_MAX_TERMS = 7, MUL_MAX_TERMS = 3, DOTN_MAX_PAIRS = 8, LIN_MAX_COEF = 
 //   w[0] bit 0 active, bit 1 second product, bits 2..4 StepType,
 //        bits 5..7 the step's largest term count (sums: terms of an op; multiplier steps: terms of an operand;
 //        ST_DOTN: products of an op, minus one; copy steps: the CopyKind), bits 8..9 sweep / reduce flags of the step,
-//        bit 10 the step reads w[3], bit 11 the step reads w[4] (informative: the kernel fetches w[3] always and w[4]
-//        where a sum has seven terms), sums: bits 12..15 the shifted zero B (signed),
+//        bit 10 the descriptor also holds the sum of the step that followed (see pack_second_sum),
+//        sums: bits 12..15 the shifted zero B (signed),
 //        multiplier and sum steps: destination slot in bits 16..22, bit 23 some lane of the step
 //        carries a fill, bit 24 some lane carries a spill; copy steps: bits 16..31 zero
 //   multiplier steps: w[1 + t], t = 0..2: term t of the operands a, b, c, d in bytes 0..3: LDS slot in bits 0..6,
@@ -108,9 +108,6 @@ inline PackedDesc pack_desc(const StepHdr& h, const OpDesc& d) {
         p.w[2] = d.w[0];  // (a copy's destination may be any slot of a global array: a field of its own)
     } else {
         p.w[0] |= (uint32_t)d.w[0] << 16;
-        // which of the words beyond w[2] the step's lanes have to fetch
-        if (h.type == ST_LIN || h.type == ST_DOTN ? nterms_step > 4 : nterms_step > 2) p.w[0] |= 1u << 10;
-        if ((h.type == ST_LIN || h.type == ST_DOTN) && nterms_step > 6) p.w[0] |= 1u << 11;
         p.w[0] |= ((h.max_terms >> 16) & 3u) << 23;
         if (h.type == ST_LIN) {
             const uint32_t B = (d.hdr >> 24) & 0xfu;
@@ -136,6 +133,25 @@ inline PackedDesc pack_desc(const StepHdr& h, const OpDesc& d) {
         }
     }
     return p;
+}
+
+// A sum step of at most four terms per sum that carries no copies can share the descriptors, and so the dispatch,
+// of the step before it (a multiplier step, or a sum step of at most six terms): the kernel runs the first step's
+// operation, then the second step's sum, in program order.  The second sum sits in the words the first leaves free:
+//   w[4] bits 0..6 destination slot, 8..11 its shifted zero B, 12..14 the second step's largest term count,
+//        15..16 the second step's sweep / reduce flags
+//   w[6], w[7] its terms, as w[1], w[2] of a sum step
+// (Measured with sums of up to six terms as well, the fifth and sixth in w[3] where the first step leaves it free:
+// more pairs, but the longer sum routine in that place costs more than they save.)
+inline bool can_take_second_sum(const StepHdr& first, const StepHdr& second) {
+    const bool first_ok = first.type == ST_FMUL || first.type == ST_DOT2 || (first.type == ST_LIN && (first.max_terms & 0xffu) <= 6);
+    return first_ok && second.type == ST_LIN && (second.max_terms & 0xffu) <= 4 && ((second.max_terms >> 16) & 3u) == 0;
+}
+inline void pack_second_sum(PackedDesc& p, const StepHdr& h, const OpDesc& d) {
+    p.w[0] |= 1u << 10;
+    p.w[4] = (uint32_t)(d.w[0] & 0x7fu) | (((d.hdr >> 24) & 0xfu) << 8) | ((h.max_terms & 7u) << 12) | (((h.max_terms >> 8) & 3u) << 15);
+    p.w[6] = p.w[7] = 0;
+    for (int i = 0; i < 4; i++) p.w[6 + i / 2] |= (uint32_t)(d.w[1 + i] & 0x7fffu) << (16 * (i % 2));
 }
 
 // Constant table ids (each entry 14 digits of 28 bits; Montgomery factor 2^392 unless noted).

@@ -157,6 +157,8 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
         // registers came from global loads themselves, and a wait for them placed after the carried fills' loads
         // would wait for those too.  (A sum's seventh term is fetched by the sums that have one.)
         const u32 d3 = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur.w);
+        u32 second_w = 0;  // a second step's sum riding in this step's descriptors: its header word
+        if (hx & (1u << 10)) second_w = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur_hi.x);
         // (the spilled value's registers stay reserved until the step ends, see there: gfx9 has one counter for
         // loads and stores, and reusing a register a store still reads from means waiting for that store, which,
         // the counter being in order, means waiting for the fills' loads issued before it)
@@ -205,18 +207,19 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
             }
         }
         // Multiplier and sum steps are branch-free: idle lanes read the ZERO slot and store to TRASH.
-        if (type == ST_LIN) {  // most frequent first
-            // acc = sum of k * x over the op's terms, k a signed 8-bit coefficient: one multiply-add per digit
-            // (64-bit accumulators whose low halves are the digits; the high halves mean nothing).  The loads
-            // of up to four terms are issued together so their latencies overlap.  Sums shorter than the
-            // step's longest are padded with 0 * ZERO.
-            // the shifted zero a sum starts from: B * 2^28 on digit 0, B * 2^28 - B on digits 1..12, -B on top
+        // A sum: dst = sum of k * x over the op's terms, k a signed 8-bit coefficient: one multiply-add per digit
+        // (64-bit accumulators whose low halves are the digits; the high halves mean nothing).  The loads
+        // of up to four terms are issued together so their latencies overlap.  Sums shorter than the
+        // step's longest are padded with 0 * ZERO.  t01, t23, t45: the terms' descriptor words (a seventh term
+        // is fetched here); B: the shifted zero the sum starts from (B * 2^28 on digit 0, B * 2^28 - B on digits
+        // 1..12, -B on top); LONG = false leaves out the code for more than four terms.
+        auto run_sum = [&](auto long_tag, u32 t01, u32 t23, u32 t45, int B, u32 nterms, u32 fl, u32 to) {
+            constexpr bool LONG = decltype(long_tag)::value;
             auto COEF = [](u32 w) -> u32 { return (u32)((int)(w << 17) >> 24); };  // bits 7..14, sign-extended
             u64 acc[D28];
-            const int B = (int)(dx << 16) >> 28;  // bits 12..15, signed
             const u64 z0 = (u32)(B << 28), zm = (u32)((B << 28) - B), zt = (u32)(-B);
-            u32 d4 = 0;  // the seventh term
-            auto TERM = [&](int i) -> u32 { return ((i < 2 ? dy : (i < 4 ? dz : (i < 6 ? d3 : d4))) >> ((i & 1) * 16)) & 0x7fffu; };
+            u32 t6 = 0;  // the seventh term
+            auto TERM = [&](int i) -> u32 { return ((i < 2 ? t01 : (i < 4 ? t23 : (i < 6 ? t45 : t6))) >> ((i & 1) * 16)) & 0x7fffu; };
             auto terms = [&](auto first_tag, auto count_tag) {
                 constexpr int T0 = decltype(first_tag)::value, N = decltype(count_tag)::value;
                 u32 x[N][D28], k[N];
@@ -235,28 +238,31 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
 #define BLS381_IC(n) std::integral_constant<int, n>()
             // (uniform; written as nested two-way branches: a switch comes out of the compiler as a chain of
             // scalar flag updates)
-            if (max_terms <= 4) {
-                if (max_terms <= 2) {
-                    if (max_terms <= 1) terms(BLS381_IC(0), BLS381_IC(1));
+            if (!LONG || nterms <= 4) {
+                if (nterms <= 2) {
+                    if (nterms <= 1) terms(BLS381_IC(0), BLS381_IC(1));
                     else terms(BLS381_IC(0), BLS381_IC(2));
                 } else {
-                    if (max_terms == 3) terms(BLS381_IC(0), BLS381_IC(3));
+                    if (nterms == 3) terms(BLS381_IC(0), BLS381_IC(3));
                     else terms(BLS381_IC(0), BLS381_IC(4));
                 }
             } else {
-                if (max_terms > 6) d4 = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur_hi.x);
+                if (nterms > 6) t6 = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur_hi.x);
                 terms(BLS381_IC(0), BLS381_IC(4));
-                if (max_terms == 5) terms(BLS381_IC(4), BLS381_IC(1));
-                else if (max_terms == 6) terms(BLS381_IC(4), BLS381_IC(2));
+                if (nterms == 5) terms(BLS381_IC(4), BLS381_IC(1));
+                else if (nterms == 6) terms(BLS381_IC(4), BLS381_IC(2));
                 else terms(BLS381_IC(4), BLS381_IC(3));
             }
 #undef BLS381_IC
             u32 r[D28];
 #pragma unroll
             for (int i = 0; i < D28; i++) r[i] = (u32)acc[i];
-            if (flags & 2u) reduce28(r);  // sweeps as well
-            else if (flags) normalise28(r);
-            lds_store(dst, r);
+            if (fl & 2u) reduce28(r);  // sweeps as well
+            else if (fl) normalise28(r);
+            lds_store(to, r);
+        };
+        if (type == ST_LIN) {  // most frequent first
+            run_sum(std::true_type(), dy, dz, d3, (int)(dx << 16) >> 28 /* bits 12..15, signed */, max_terms, flags, dst);
         } else if (K == 6 && type == ST_DOTN) {  // (compiled into the 6-lane interpreter only)
             // dst = (sum over t of a_t * (+-b_t)) / 2^392 with one reduction.  Operand scanning: every product of
             // two digits goes to its column's 64-bit accumulator; the operands of product t + 1 are loaded while
@@ -456,6 +462,15 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
                 lds_store(dw & 0x7fu, pf);
             }
         }
+        }
+        // The sum of the step that followed, riding in this step's descriptors (see pack_second_sum): it runs after
+        // this step's own operation has stored its result and the step's carried fill has landed (fills ride on the
+        // step before their first use), as it would in a step of its own.
+        if (hx & (1u << 10)) {
+            const u32 t01 = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur_hi.z), t23 = (u32)__builtin_amdgcn_ds_bpermute(self, (int)cur_hi.w);
+            const u32 sh = (u32)__builtin_amdgcn_readfirstlane((int)second_w);
+            run_sum(std::false_type(), t01, t23, 0u, (int)(second_w << 20) >> 28 /* bits 8..11, signed */, (sh >> 12) & 7u, (sh >> 15) & 3u,
+                    second_w & 0x7fu);
         }
       }
       cur = nxt; cur_hi = nxt_hi;
