@@ -527,12 +527,13 @@ def test_other_lane_group_geometries(lanes, slots):
 
 
 @pytest.mark.parametrize("knob,value", [("BLS381_REDUCE_SIBLINGS", "0"), ("BLS381_NO_PIGGYBACK", "1"), ("BLS381_WINDOW", "200"),
-                                        ("BLS381_ABSORB_TERMS", "1"), ("BLS381_VB_EAGER", "50")])
+                                        ("BLS381_ABSORB_TERMS", "1"), ("BLS381_VB_EAGER", "50"), ("BLS381_NO_STEP_PAIRS", "1")])
 def test_other_schedules_give_the_same_values(ctx, knob, value, monkeypatch):
     """The scheduler's policies (which sums are reduced together, copies riding on compute steps or in steps of their
     own, the look-ahead window, sums folded into multiplier operands or not, eager reductions) change the step programs,
-    never the values: a context built under another policy returns the default context's bytes for pairings, Miller
-    values and final exponentiations of arbitrary input."""
+    never the values, and neither does running every sum step on descriptors of its own (BLS381_NO_STEP_PAIRS): a context
+    built under another policy returns the default context's bytes for pairings, Miller values and final exponentiations
+    of arbitrary input."""
     import plonky2_bls12_381_pairing_amd as B
     ps, qs = H.random_pairs(37, 4242)
     g1, g2 = H.g1_array(ps), H.g2_array(qs)
