@@ -54,6 +54,7 @@ static void fill_vm_constants(std::vector<uint32_t>& c) {
 static Dag build_named(const std::string& which, int K) {
     set_lazy_products_for(K);
     if (which == "miller") return build_miller();
+    if (which == "millers") return build_miller_scaled();
     if (which == "g2prep") return build_g2_prepare();
     if (which == "millerfq") return build_miller_fixed_q();
     if (which == "miller2") return build_miller_two_pairs();
@@ -77,7 +78,7 @@ static Dag build_named(const std::string& which, int K) {
     }
     throw std::runtime_error("unknown program " + which);
 }
-static const char* ALL_PROGRAMS[] = {"miller", "millerfq", "miller2", "g2prep", "ell",  "fe1",     "fe2",   "easy2",
+static const char* ALL_PROGRAMS[] = {"miller", "millers", "millerfq", "miller2", "g2prep", "ell",  "fe1",     "fe2",   "easy2",
                                      "hardgen", "inv1",   "inv2", "fq12mul", "frob1", "frob2"};
 
 static bool valid_k(int K) { return K == 6 || K == 8 || K == 9 || K == 12 || K == 16; }
@@ -376,7 +377,7 @@ static hipError_t launch_vm_k(bls381_ctx* c, const DevProgram& p, const uint4* g
                               int npad) {
     if (c->d_prof) return launch_vm_kt<K, TAG_PROFILE>(c, p, gin, gout, gtmp, n, npad);
     const std::string base = base_name(p.host.name);
-    if (base == "miller" || base == "millerfq") return launch_vm_kt<K, TAG_MILLER>(c, p, gin, gout, gtmp, n, npad);
+    if (base == "miller" || base == "millers" || base == "millerfq") return launch_vm_kt<K, TAG_MILLER>(c, p, gin, gout, gtmp, n, npad);
     if (base == "fe2") return launch_vm_kt<K, TAG_FINAL_EXP>(c, p, gin, gout, gtmp, n, npad);
     return launch_vm_kt<K, TAG_AUX>(c, p, gin, gout, gtmp, n, npad);
 }
@@ -463,7 +464,9 @@ static int miller_dev_enqueue(bls381_ctx* c, const uint64_t* g1, const uint64_t*
     rc = pack(c, g2, c->bufA.p, m, npad, 4, 2);
     if (rc) return rc;
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    rc = run_program(c, "miller", c->bufA.p, c->bufB.p, m, npad);
+    // (a Miller value that goes on to the final exponentiation may differ from the reference's by a factor in Fq:
+    // the loop without the halvings of the G2 doublings, see build_miller_scaled)
+    rc = run_program(c, with_final_exp ? "millers" : "miller", c->bufA.p, c->bufB.p, m, npad);
     if (rc) return rc;
     if (flags) {
         hipLaunchKernelGGL(set_one_where_flag, dim3((m + 255) / 256), dim3(256), 0, c->stream, (uint4*)c->bufB.p, flags,
@@ -599,8 +602,8 @@ extern "C" int bls381_ctx_reserve(bls381_ctx* c, size_t max_items) {
     HIPCHK(c->bufB.ensure(soa_bytes(12, npad)));
     HIPCHK(c->bufC.ensure(soa_bytes(FE_CARRY, npad)));
     size_t tmp = 0;
-    std::vector<std::string> names = {"miller", "fe1", "fe2"};
-    if (c->auto_geometry) for (const char* nm : {"miller@16", "fe1@16", "fe2@16"}) names.push_back(nm);
+    std::vector<std::string> names = {"miller", "millers", "fe1", "fe2"};
+    if (c->auto_geometry) for (const char* nm : {"miller@16", "millers@16", "fe1@16", "fe2@16"}) names.push_back(nm);
     for (const std::string& nm : names) {
         if (!c->progs.count(nm)) { int rc = upload_program(c, nm); if (rc) return rc; }
         tmp = std::max(tmp, spill_bytes(c->progs[nm], npad));
@@ -622,7 +625,7 @@ extern "C" int bls381_pairing_batch_dev_noalloc(bls381_ctx* c, const uint64_t* g
         return fail(BLS381_ERR_INVALID, "bls381_pairing_batch_dev_noalloc takes at most " + std::to_string((int)NOALLOC_MAX_PAIRS) +
                                             " pairs per call (got " + std::to_string(n) + ")");
     const int m = (int)n, npad = pad_elems(n);
-    const char* names[3] = {"miller", "fe1", "fe2"};
+    const char* names[3] = {"millers", "fe1", "fe2"};
     size_t tmp = 0;
     for (const char* nm : names) {
         auto it = c->progs.find(nm);
@@ -640,7 +643,7 @@ extern "C" int bls381_pairing_batch_dev_noalloc(bls381_ctx* c, const uint64_t* g
     int rc;
     if ((rc = pack(c, g1, bA, m, npad, 2, 0))) return rc;
     if ((rc = pack(c, g2, bA, m, npad, 4, 2))) return rc;
-    if ((rc = run_program_on(c, "miller", bA, bB, bT, m, npad))) return rc;
+    if ((rc = run_program_on(c, "millers", bA, bB, bT, m, npad))) return rc;
     if (flags) {
         hipLaunchKernelGGL(set_one_where_flag, dim3((m + 255) / 256), dim3(256), 0, c->stream, (uint4*)bB, flags, c->d_consts, m, npad);
         HIPCHK(hipGetLastError());

@@ -88,6 +88,9 @@ void set_lazy_products_for(int K);
 // multi_miller_loop_native for one pair, conjugated.      /root/reference/src/native/miller_loop.rs:121-162
 // gin: G1 (2) + G2 (4); gout: Fq12 (12).
 Dag build_miller();
+// The same loop for callers that go on to the final exponentiation: G2 doublings without the halvings
+// (Tower::g2_double_scaled).  Its value differs from the reference's Miller value by a factor in Fq.
+Dag build_miller_scaled();
 // G2Prepared::from: the 68 line coefficients.                /root/reference/src/native/miller_loop.rs:90-119
 // gin: G2 (4); gout: 68 * 6 (coefficient k, Fq2 j, component c at 6*k + 2*j + c).
 Dag build_g2_prepare();

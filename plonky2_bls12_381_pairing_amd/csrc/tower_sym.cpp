@@ -422,6 +422,28 @@ Tower::EllCoeff Tower::g2_double(G2Proj& r, SFp two_inv) {
     return EllCoeff{i, lin2({{j, 1}, {j, 1}, {j, 1}}), neg(h)};
 }
 
+// g2_double with (x, y, z) -> 4 * (x', y', z') of the reference's step: a = x y (twice the reference's), g = b + f
+// (twice), so 4 x' = 2 a (b - f), 4 y' = g^2 - 12 e^2, 4 z' = 4 b h.  With R = lambda * (the reference's R), lambda
+// in Fq, every line coefficient (e - b, 3 x^2, -h) is lambda^2 times the reference's.
+Tower::EllCoeff Tower::g2_double_scaled(G2Proj& r) {
+    SFq2 a = mul(r.x, r.y);
+    SFq2 b = sqr(r.y);
+    SFq2 c = sqr(r.z);
+    SFq2 c12 = lin2({{c, 12}});
+    SFq2 e = mul_xi(c12);
+    SFq2 f = lin2({{e, 3}});
+    SFq2 g = add(b, f);
+    SFq2 h = sub(sqr(add(r.y, r.z)), add(b, c));
+    SFq2 i = sub(e, b);
+    SFq2 j = sqr(r.x);
+    SFq2 e_square = sqr(e);
+    SFq2 nx = lin2({{mul(a, sub(b, f)), 2}});
+    SFq2 ny = lin2({{sqr(g), 1}, {e_square, -12}});
+    SFq2 nz = lin2({{mul(b, h), 4}});
+    r = G2Proj{nx, ny, nz};
+    return EllCoeff{i, lin2({{j, 3}}), neg(h)};
+}
+
 // /root/reference/src/native/miller_loop.rs:71-87
 Tower::EllCoeff Tower::g2_add(G2Proj& r, const SFq2& qx, const SFq2& qy) {
     SFq2 theta = sub(r.y, mul(qy, r.z));
@@ -461,7 +483,7 @@ void Tower::out12(const SFq12& a, int base) {
 // ------------------------------------------------------------------ builders
 // The Miller loop walks the bits of |x| below the top one, MSB first
 // (BitIteratorBE::without_leading_zeros([BLS_X]).skip(1)): 63 doublings, 5 additions.
-static void miller_body(Tower& T, SFq12& f, bool emit_coeffs, int q_base, int p_base) {
+static void miller_body(Tower& T, SFq12& f, bool emit_coeffs, int q_base, int p_base, bool scaled = false) {
     Dag& d = T.dag();
     (void)d;
     // each input is converted once (a multiplication) and then lives like any other value
@@ -471,8 +493,7 @@ static void miller_body(Tower& T, SFq12& f, bool emit_coeffs, int q_base, int p_
     Tower::G2Proj r{qx, qy, T.one2()};
     int k = 0;
     for (int i = 62; i >= 0; i--) {
-        SFp two_inv = T.cst(C_TWO_INV);
-        Tower::EllCoeff c = T.g2_double(r, two_inv);
+        Tower::EllCoeff c = scaled ? T.g2_double_scaled(r) : T.g2_double(r, T.cst(C_TWO_INV));
         if (emit_coeffs) {
             T.out(c.c0.c0, 6 * k + 0); T.out(c.c0.c1, 6 * k + 1);
             T.out(c.c1.c0, 6 * k + 2); T.out(c.c1.c1, 6 * k + 3);
@@ -504,6 +525,18 @@ Dag build_miller() {
     SFq12 f = T.one12();
     miller_body(T, f, false, /*q_base=*/2, /*p_base=*/0);
     f = T.conj(f);  // BLS_X_IS_NEGATIVE, /root/reference/src/native/miller_loop.rs:157-159
+    T.out12(f, 0);
+    d.optimise();
+    return d;
+}
+
+Dag build_miller_scaled() {
+    Dag d;
+    d.n_in = 6; d.n_out = 12;
+    Tower T(d);
+    SFq12 f = T.one12();
+    miller_body(T, f, false, /*q_base=*/2, /*p_base=*/0, /*scaled=*/true);
+    f = T.conj(f);
     T.out12(f, 0);
     d.optimise();
     return d;

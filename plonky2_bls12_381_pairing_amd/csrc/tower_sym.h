@@ -119,6 +119,9 @@ class Tower {
     struct G2Proj { SFq2 x, y, z; };
     struct EllCoeff { SFq2 c0, c1, c2; };
     EllCoeff g2_double(G2Proj& r, SFp two_inv);
+    // The same step with R kept at four times the reference's coordinates per doubling (no halvings): the same
+    // projective point, line coefficients scaled by an element of Fq, which the final exponentiation removes.
+    EllCoeff g2_double_scaled(G2Proj& r);
     EllCoeff g2_add(G2Proj& r, const SFq2& qx, const SFq2& qy);
     SFq12 ell(const SFq12& f, const EllCoeff& c, SFp px, SFp py);
     SFq12 hard_part(const SFq12& r, bool cyclotomic);

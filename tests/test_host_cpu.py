@@ -99,6 +99,16 @@ def test_miller_and_final_exp_programs(K, slots):
     mid[0] = M(R.fq_inv(F(mid[0])))                       # the Fp inversion kernel's job
     out = S.run_program(S.get_program("fe2", K, slots), mid)
     assert R.fq12_from_flat_ark([F(x) for x in out]) == R.native_pairing([p], [q])
+    if K == 8:
+        # the loop the pairing calls run (G2 doublings without their halvings): another Miller value, off by a factor in
+        # Fq, and the same pairing
+        out = S.run_program(S.get_program("millers", K, slots), [M(p[0]), M(p[1]), M(q[0][0]), M(q[0][1]), M(q[1][0]), M(q[1][1])])
+        scaled = R.fq12_from_flat_ark([F(x) for x in out])
+        assert scaled != ml
+        mid = S.run_program(S.get_program("fe1", K, slots), [M(x) for x in R.fq12_flatten_ark(scaled)])
+        mid[0] = M(R.fq_inv(F(mid[0])))
+        out = S.run_program(S.get_program("fe2", K, slots), mid)
+        assert R.fq12_from_flat_ark([F(x) for x in out]) == R.native_pairing([p], [q])
 
 
 def test_auxiliary_programs():
