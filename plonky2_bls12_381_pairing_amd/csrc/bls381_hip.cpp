@@ -58,6 +58,7 @@ static Dag build_named(const std::string& which, int K) {
     if (which == "g2prep") return build_g2_prepare();
     if (which == "millerfq") return build_miller_fixed_q();
     if (which == "miller2") return build_miller_two_pairs();
+    if (which == "miller2s") return build_miller_two_pairs(true);
     if (which == "ell") return build_ell();
     if (which == "fe1") return build_final_exp_part1();
     if (which == "fe2") return build_final_exp_part2(true);
@@ -78,7 +79,7 @@ static Dag build_named(const std::string& which, int K) {
     }
     throw std::runtime_error("unknown program " + which);
 }
-static const char* ALL_PROGRAMS[] = {"miller", "millers", "millerfq", "miller2", "g2prep", "ell",  "fe1",     "fe2",   "easy2",
+static const char* ALL_PROGRAMS[] = {"miller", "millers", "millerfq", "miller2", "miller2s", "g2prep", "ell",  "fe1",     "fe2",   "easy2",
                                      "hardgen", "inv1",   "inv2", "fq12mul", "frob1", "frob2"};
 
 static bool valid_k(int K) { return K == 6 || K == 8 || K == 9 || K == 12 || K == 16; }
@@ -184,7 +185,7 @@ struct bls381_ctx {
 static std::string base_name(const std::string& which) { return which.substr(0, which.find('@')); }
 static void program_geometry(const bls381_ctx* c, const std::string& which, int& K, int& slots) {
     K = c->K; slots = c->lds_slots;
-    if (c->auto_geometry && (which == "miller2" || which.find("@16") != std::string::npos)) { K = 16; slots = default_slots(16); }
+    if (c->auto_geometry && (which == "miller2" || which == "miller2s" || which.find("@16") != std::string::npos)) { K = 16; slots = default_slots(16); }
 }
 
 // Synthetic programs for timing one step kind in isolation: 1,000 identical steps with every lane
@@ -402,7 +403,7 @@ static int run_program_on(bls381_ctx* c, const std::string& which, const void* g
 static size_t spill_bytes(const DevProgram& p, int npad) { return (size_t)std::max(1, p.host.n_tmp_slots) * 56 * npad; }
 static int run_program(bls381_ctx* c, const char* which_c, const void* gin, void* gout, int n, int npad) {
     std::string which = which_c;
-    if (c->auto_geometry && n <= SMALL_BATCH && which != "miller2" && which.rfind("t_", 0) != 0) {
+    if (c->auto_geometry && n <= SMALL_BATCH && which != "miller2" && which != "miller2s" && which.rfind("t_", 0) != 0) {
         which += "@16";
         if (!c->progs.count(which)) {
             int rc = upload_program(c, which);
@@ -523,7 +524,8 @@ static int two_pairs_dev_locked(bls381_ctx* c, const uint64_t* g1a, const uint64
         if ((rc = pack(c, g1b + off * 12, c->bufA.p, m, npad, 2, 6))) return rc;
         if ((rc = pack(c, g2b + off * 24, c->bufA.p, m, npad, 4, 8))) return rc;
         HIPCHK(hipEventRecord(c->ev[1], c->stream));
-        if ((rc = run_program(c, "miller2", c->bufA.p, c->bufB.p, m, npad))) return rc;
+        // (values that go on to the final exponentiation: the loops without the halvings of the G2 doublings)
+        if ((rc = run_program(c, with_final_exp ? "miller2s" : "miller2", c->bufA.p, c->bufB.p, m, npad))) return rc;
         if (flags) {
             // Items that skip one pair (a point at infinity) need the other pair's own Miller value.  They are
             // picked out on the device (no copy of the flags to the host, no synchronisation): their remaining
@@ -540,7 +542,7 @@ static int two_pairs_dev_locked(bls381_ctx* c, const uint64_t* g1a, const uint64
                                flags + off, m, npad, (uint4*)c->bufD.p, list, count);
             HIPCHK(hipGetLastError());
             c->n_dev_override = count;
-            rc = run_program(c, "miller", c->bufD.p, c->bufE.p, m, npad);
+            rc = run_program(c, with_final_exp ? "millers" : "miller", c->bufD.p, c->bufE.p, m, npad);
             c->n_dev_override = nullptr;
             if (rc) return rc;
             hipLaunchKernelGGL(scatter_one_pair_items, dim3((m + 255) / 256), dim3(256), 0, c->stream, (uint4*)c->bufB.p,

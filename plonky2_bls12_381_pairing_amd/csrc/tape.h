@@ -97,7 +97,7 @@ Dag build_g2_prepare();
 // The Miller loop with the 68 line coefficients taken from constants C_COUNT .. C_COUNT + 408
 // (a prepared G2 point shared by the whole batch).  gin: G1 (2); gout: Fq12 (12).
 Dag build_miller_fixed_q();
-Dag build_miller_two_pairs();
+Dag build_miller_two_pairs(bool scaled = false);  // scaled: G2 doublings without the halvings, as build_miller_scaled
 // ell(f, coeffs, p).                                         /root/reference/src/native/miller_loop.rs:185-194
 // gin: f (12) + coeff (6) + G1 (2); gout: f (12).
 Dag build_ell();

@@ -546,7 +546,7 @@ Dag build_miller_scaled() {
 // (/root/reference/src/native/miller_loop.rs:139-156): f is squared once per bit, then multiplied by
 // each pair's line.  Equal, as a field element, to the product of the two single-pair values.
 // gin: P1 (2), Q1 (4), P2 (2), Q2 (4).
-Dag build_miller_two_pairs() {
+Dag build_miller_two_pairs(bool scaled) {
     Dag d;
     d.n_in = 12; d.n_out = 12;
     Tower T(d);
@@ -562,7 +562,7 @@ Dag build_miller_two_pairs() {
     }
     for (int i = 62; i >= 0; i--) {
         f = T.sqr(f);
-        for (int j = 0; j < 2; j++) f = T.ell(f, T.g2_double(r[j], T.cst(C_TWO_INV)), px[j], py[j]);
+        for (int j = 0; j < 2; j++) f = T.ell(f, scaled ? T.g2_double_scaled(r[j]) : T.g2_double(r[j], T.cst(C_TWO_INV)), px[j], py[j]);
         if ((BLS381_X >> i) & 1)
             for (int j = 0; j < 2; j++) f = T.ell(f, T.g2_add(r[j], qx[j], qy[j]), px[j], py[j]);
     }
