@@ -72,7 +72,8 @@ int bls381_final_exp_batch(bls381_ctx*, const uint64_t* in_fq12, size_t n, uint6
 /* native_pairing([p], [q]) for each of n independent pairs (src/native/pairing.rs:8-13).  The values are the
  * reference's; the Miller value formed on the way (never returned) differs from bls381_miller_loop_batch's by a factor
  * in Fq, which the final exponentiation removes: the G2 doublings run without their halvings.  The same holds for the
- * two-pair pairing and the signature checks; every call that returns Miller values follows the reference's formulas. */
+ * two-pair pairing, the product-form pairing (bls381_multi_pairing, bls381_multi_ctx_multi_pairing) and the signature
+ * checks; every call that returns Miller values follows the reference's formulas. */
 int bls381_pairing_batch(bls381_ctx*, const uint64_t* g1, const uint64_t* g2, const uint8_t* inf_flags, size_t n,
                          uint64_t* out_fq12);
 /* multi_miller_loop_native over all n pairs at once: one Fq12 (src/native/miller_loop.rs:121-162;

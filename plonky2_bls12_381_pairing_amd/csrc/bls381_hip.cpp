@@ -1152,7 +1152,7 @@ static int product_tree(bls381_ctx* c, const void* src, int m, int npad_src) {
 }
 
 static int multi_host(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags, size_t n,
-                      uint64_t out[72], int* is_one, bool fe) {
+                      uint64_t out[72], int* is_one, bool fe, bool scaled) {
     if (!out) return fail(BLS381_ERR_INVALID, "NULL buffer");
     if (n > (size_t)CHUNK * 16) return fail(BLS381_ERR_INVALID, "n_pairs too large");
     if (n && (!g1 || !g2)) return fail(BLS381_ERR_INVALID, "NULL buffer");
@@ -1180,7 +1180,9 @@ static int multi_host(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, con
     HIPCHK(c->user_out.ensure(soa_bytes(12, npad)));
     if ((rc = pack(c, c->user_in.p, c->bufA.p, m, npad, 2, 0))) return rc;
     if ((rc = pack(c, c->user_in2.p, c->bufA.p, m, npad, 4, 2))) return rc;
-    if ((rc = run_program(c, "miller", c->bufA.p, c->user_out.p, m, npad))) return rc;
+    // (`scaled`: the product goes on to a final exponentiation, here or in the caller, so the loops may leave out the
+    // halvings of the G2 doublings, see build_miller_scaled)
+    if ((rc = run_program(c, scaled ? "millers" : "miller", c->bufA.p, c->user_out.p, m, npad))) return rc;
     if (fdev) {
         hipLaunchKernelGGL(set_one_where_flag, dim3((m + 255) / 256), dim3(256), 0, c->stream, (uint4*)c->user_out.p,
                            fdev, c->d_consts, m, npad);
@@ -1204,12 +1206,18 @@ static int multi_host(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, con
 extern "C" int bls381_multi_miller_loop(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags,
                                         size_t n, uint64_t out[72]) {
     CTX_GUARD(c);
-    return multi_host(c, g1, g2, flags, n, out, nullptr, false);
+    return multi_host(c, g1, g2, flags, n, out, nullptr, false, false);
+}
+// a shard's share of a product that the caller exponentiates: off the exact Miller value by a factor in Fq
+static int multi_miller_loop_scaled(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags, size_t n,
+                                    uint64_t out[72]) {
+    CTX_GUARD(c);
+    return multi_host(c, g1, g2, flags, n, out, nullptr, false, true);
 }
 extern "C" int bls381_multi_pairing(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags, size_t n,
                                     uint64_t out[72], int* is_one) {
     CTX_GUARD(c);
-    return multi_host(c, g1, g2, flags, n, out, is_one, true);
+    return multi_host(c, g1, g2, flags, n, out, is_one, true, true);
 }
 extern "C" int bls381_finish_multi_pairing(bls381_ctx* c, const uint64_t* partials, size_t n, uint64_t out[72],
                                            int* is_one) {
@@ -1331,7 +1339,8 @@ static int multi_ctx_product(bls381_multi_ctx* m, const uint64_t* g1, const uint
     if (!out) return fail(BLS381_ERR_INVALID, "NULL buffer");
     std::vector<uint64_t> partials(m->ctxs.size() * 72);
     int rc = shard_run(m, n, [&](size_t k, bls381_ctx* c, size_t off, size_t cnt) {
-        return bls381_multi_miller_loop(c, SHARD_PTR(g1, 12), SHARD_PTR(g2, 24), SHARD_PTR(flags, 1), cnt, &partials[k * 72]);
+        return (fe ? multi_miller_loop_scaled : bls381_multi_miller_loop)(c, SHARD_PTR(g1, 12), SHARD_PTR(g2, 24),
+                                                                          SHARD_PTR(flags, 1), cnt, &partials[k * 72]);
     });
     if (rc) return rc;
     bls381_ctx* c = m->ctxs[0];
