@@ -1514,13 +1514,23 @@ extern "C" int bls381_debug_witness_cache_plan(int lanes_per_proof, int cache_ro
         out[0] += reads; out[1] += hits; out[3] += ops.size();
         std::vector<int64_t> entry(WCACHE_MAX_ROWS, -1);
         const auto& ls = P.level_start[ph];
+        // the level assignment: every row of the phase is made once, from rows of earlier levels (or of outside the phase)
+        const size_t row_lo = ph == 0 ? 0 : P.gen_start + 12, row_hi = ph == 0 ? P.gen_start : P.n_rows;
+        const size_t NOT_MADE = ~(size_t)0;
+        std::vector<size_t> made_in(row_hi - row_lo, NOT_MADE);
         for (size_t l = 0; l + 1 < ls.size(); l++)
             for (uint32_t i = ls[l]; i < ls[l + 1]; i += (uint32_t)lanes_per_proof) {
                 const uint32_t e = std::min(i + (uint32_t)lanes_per_proof, ls[l + 1]);
                 for (uint32_t j = i; j < e; j++) {
                     const uint32_t kind = ops[j].dst >> 28;
                     const uint32_t refs[2] = {ops[j].a, ops[j].b};
+                    const size_t row = ops[j].dst & WROW_MASK;
+                    if (row < row_lo || row >= row_hi || made_in[row - row_lo] != NOT_MADE) out[2]++;
+                    else made_in[row - row_lo] = l;
                     for (int k = 0; k < (kind == WK_NEG || kind == WK_INV ? 1 : 2); k++) {
+                        const size_t src = refs[k] & WROW_MASK;
+                        if ((refs[k] >> 30) == 0 && src >= row_lo && src < row_hi && (made_in[src - row_lo] == NOT_MADE || made_in[src - row_lo] >= l))
+                            out[2]++;
                         if ((refs[k] >> 30) != 0) { if (refs[k] & WCACHE_FLAG) out[2]++; continue; }
                         if (!(refs[k] & WCACHE_FLAG)) continue;
                         const uint32_t sl = (refs[k] >> WCACHE_SLOT_SHIFT) & WCACHE_SLOT_MASK;
@@ -1540,6 +1550,7 @@ extern "C" int bls381_debug_witness_cache_plan(int lanes_per_proof, int cache_ro
                     entry[sl] = ops[j].dst & WROW_MASK;
                 }
             }
+        for (size_t m : made_in) if (m == NOT_MADE) out[2]++;
     }
     return 0;
 }

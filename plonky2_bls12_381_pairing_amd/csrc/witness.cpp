@@ -4,6 +4,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 
 #include "bls381_constants.h"
 #include "fp_dev.h"
@@ -27,6 +30,12 @@ struct WB {  // builder: every method appends one row
     uint32_t mul(uint32_t a, uint32_t b) { return emit(WK_MUL, a, b); }
     uint32_t neg(uint32_t a) { return emit(WK_NEG, a, a); }
 };
+// rows of a level that the lanes of one proof take together (BLS381_WIT_GROUP: 0 or 1 = every row at its earliest level)
+inline int env_group() {
+    const char* e = getenv("BLS381_WIT_GROUP");
+    const int g = e ? atoi(e) : 16;
+    return g < 0 || g > 64 ? 16 : g;
+}
 inline uint32_t cst(int id) { return WREF_CONST | (uint32_t)id; }
 inline uint32_t inp(int id) { return WREF_INPUT | (uint32_t)id; }
 
@@ -243,7 +252,7 @@ F12 pow_target(WB& w, const F12& a) {                                           
     return res;
 }
 
-WitnessProgram build_program() {
+WitnessProgram build_program(int group) {
     WB w;
     WitnessProgram P;
     // G2PreparedTarget::from, curves/g2.rs:148-178
@@ -309,6 +318,7 @@ WitnessProgram build_program() {
     y1 = mul(w, y1, y0);
     (void)mul(w, r2, y1);
 
+    P.group = group;
     P.n_rows = w.kinds.size();
     P.kinds = w.kinds;
     for (uint8_t kd : w.kinds) P.counts[kd]++;
@@ -333,8 +343,50 @@ WitnessProgram build_program() {
             level[i] = l;
             maxl = std::max(maxl, l);
         }
+        // Which level a row runs in.  The lanes of a proof take a level's rows `group` at a time, and a group that
+        // holds one product costs as much as a full group of products, so rows that can wait are held back until
+        // they fill a group: every row has a latest level (the one before its first consumer's latest level), a row
+        // at its latest level must run, and the others ready by then fill that group up, or run when a whole group
+        // of them is ready.  Products first in every level, then the rest, so that few groups hold both.
         std::vector<std::vector<uint32_t>> by(maxl + 1);
-        for (size_t i = lo; i < hi; i++) by[level[i]].push_back((uint32_t)i);
+        if (group <= 1) {
+            for (size_t i = lo; i < hi; i++) by[level[i]].push_back((uint32_t)i);
+        } else {
+            auto in_phase = [&](uint32_t ref) { return (ref >> 30) == 0 && (ref & WREF_MASK) >= lo && (ref & WREF_MASK) < hi; };
+            std::vector<uint32_t> late(hi - lo, maxl), npred(hi - lo, 0), ready_at(hi - lo, 0);
+            std::vector<std::vector<uint32_t>> users(hi - lo);
+            for (size_t i = lo; i < hi; i++) {
+                uint32_t refs[2] = {w.ra[i], w.rb[i]};
+                for (int k = 0; k < (refs[0] == refs[1] ? 1 : 2); k++)
+                    if (in_phase(refs[k])) { users[(refs[k] & WREF_MASK) - lo].push_back((uint32_t)i); npred[i - lo]++; }
+            }
+            for (size_t i = hi; i-- > lo;)
+                for (uint32_t u : users[i - lo]) late[i - lo] = std::min(late[i - lo], late[u - lo] - 1);
+            std::vector<std::vector<uint32_t>> arrives(maxl + 2);
+            for (size_t i = lo; i < hi; i++) if (!npred[i - lo]) arrives[0].push_back((uint32_t)i);
+            std::vector<uint32_t> pool[2];  // waiting rows: products, others
+            for (uint32_t l = 0; l <= maxl; l++) {
+                for (uint32_t i : arrives[l]) pool[w.kinds[i] == WK_MUL ? 0 : 1].push_back(i);
+                for (int k = 0; k < 2; k++) {
+                    auto& pl = pool[k];
+                    std::stable_sort(pl.begin(), pl.end(), [&](uint32_t x, uint32_t y) { return late[x - lo] < late[y - lo]; });
+                    size_t must = 0;
+                    while (must < pl.size() && late[pl[must] - lo] <= l) must++;
+                    size_t take = must ? (must + group - 1) / group * group : pl.size() / group * group;
+                    take = std::min(take, pl.size());
+                    for (size_t q = 0; q < take; q++) {
+                        const uint32_t i = pl[q];
+                        by[l].push_back(i);
+                        for (uint32_t u : users[i - lo]) {
+                            ready_at[u - lo] = std::max(ready_at[u - lo], l + 1);
+                            if (--npred[u - lo] == 0) arrives[ready_at[u - lo]].push_back(u);
+                        }
+                    }
+                    pl.erase(pl.begin(), pl.begin() + take);
+                }
+            }
+            if (!pool[0].empty() || !pool[1].empty()) { fprintf(stderr, "witness level assignment left rows over\n"); abort(); }
+        }
         P.level_start[phase].push_back(0);
         for (auto& rows : by) {
             for (uint32_t i : rows) P.ops[phase].push_back(WitnessOp{i | ((uint32_t)w.kinds[i] << 28), w.ra[i], w.rb[i]});
@@ -348,6 +400,14 @@ WitnessProgram build_program() {
             }
             fprintf(stderr, "witness phase %d: %zu rows in %zu levels; widths <=4:%zu <=8:%zu <=16:%zu <=32:%zu <=64:%zu <=128:%zu <=256:%zu more:%zu\n",
                     phase, hi - lo, by.size(), hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
+            size_t iters = 0, with_mul = 0, with_lin = 0, mixed = 0;
+            for (auto& rows : by)
+                for (size_t j = 0; j < rows.size(); j += 16) {
+                    bool m = false, l = false;
+                    for (size_t q = j; q < std::min(rows.size(), j + (size_t)16); q++) (w.kinds[rows[q]] == WK_MUL ? m : l) = true;
+                    iters++; with_mul += m; with_lin += l; mixed += m && l;
+                }
+            fprintf(stderr, "  sixteen rows at a time: %zu groups, %zu with a product, %zu with other rows, %zu with both\n", iters, with_mul, with_lin, mixed);
         }
     }
     return P;
@@ -429,8 +489,14 @@ std::vector<WitnessOp> plan_row_cache(const WitnessProgram& P, int phase, int lp
 }
 
 const WitnessProgram& witness_program() {
-    static WitnessProgram P = build_program();
-    return P;
+    // one program per level assignment asked for (BLS381_WIT_GROUP), built on first use and kept
+    static std::mutex mu;
+    static std::map<int, std::unique_ptr<WitnessProgram>> built;
+    const int group = env_group();
+    std::lock_guard<std::mutex> g(mu);
+    auto& p = built[group];
+    if (!p) p.reset(new WitnessProgram(build_program(group)));
+    return *p;
 }
 
 // ================================================================= device
@@ -680,6 +746,10 @@ static hipError_t ensure(void*& p, size_t& have, size_t need) {
 int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint64_t* g1, const uint64_t* g2, size_t n,
                        uint32_t* trace, std::string& err, bool on_device, const WitnessAux* aux) {
     const WitnessProgram& P = witness_program();
+    if (uploaded_ && prog_group_ != P.group) {  // another level assignment than the one uploaded
+        WCHK(hipStreamSynchronize(stream));
+        release();
+    }
     if (!uploaded_) {
         release();  // an earlier upload that failed half-way leaves nothing behind
         for (int ph = 0; ph < 2; ph++) {
@@ -697,12 +767,15 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         WCHK(hipMalloc((void**)&d_mul_index_, P.n_rows * 4));
         WCHK(hipMemcpy(d_mul_index_, P.mul_index.data(), P.n_rows * 4, hipMemcpyHostToDevice));
         uploaded_ = true;
+        prog_group_ = P.group;
     }
     // Sixteen lanes per proof, four proofs per one-wave workgroup: dependency levels are about 35 rows wide
     // (a third of them at most 16), so wider groups mostly idle at their barriers, and the kernel hides its load
     // latency only by the number of proofs in flight (measured, proofs/s: 256 lanes per proof x 512 proofs per
     // pass 29 k; 64 lanes x 16,384 104 k; 32 lanes 145 k; 16 lanes 167 k; 8 lanes 162 k; with the Barrett
-    // product in place of two Montgomery products 190 k at 16 lanes).
+    // product in place of two Montgomery products 190 k at 16 lanes).  The level assignment of build_program fills
+    // those 16 lanes: groups of 16 rows that hold a product 8,092 -> 5,159 of at least 4,416, the two kernels of
+    // 16,384 proofs 70 -> 61 ms.
     // The staging buffer of the host-pointer form (6.8 MB per proof) keeps that form to 1,024 per pass;
     // its copy back to the host is what bounds it anyway.
     size_t CH = on_device ? 16384 : 1024;

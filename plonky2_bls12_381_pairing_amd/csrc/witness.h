@@ -43,6 +43,7 @@ enum WitnessConst {
 };
 
 struct WitnessProgram {
+    int group = 0;                        // rows of a level that run together, as the level assignment assumed (0: none)
     size_t n_rows = 0;
     std::vector<uint8_t> kinds;           // per row
     size_t gen_start = 0;                 // first of the 12 generator-output rows
@@ -79,6 +80,7 @@ class WitnessDevice {
 
    private:
     bool uploaded_ = false;
+    int prog_group_ = -1;
     WitnessOp* d_ops_[2] = {nullptr, nullptr};   // as built (the auxiliary-value kernel reads these)
     WitnessOp* d_plan_[2] = {nullptr, nullptr};  // with the row-cache plan for (plan_lpp_, plan_rows_)
     int plan_lpp_ = -1, plan_rows_ = -1;

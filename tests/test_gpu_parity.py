@@ -347,6 +347,19 @@ def test_witness_kernel_geometries(ctx, cache, lpp, monkeypatch):
     assert np.array_equal(ctx.pairing_witness_batch(g1, g2), want)
 
 
+@pytest.mark.parametrize("group", ["0", "8", "64"])
+def test_witness_level_assignments(ctx, group, monkeypatch):
+    """Rows of the trace that can wait are held back until they fill a group of the lanes of a proof (16 by default):
+    the same trace bytes with every row at its earliest level and with groups of other sizes."""
+    ps, qs = H.random_pairs(5, 4242)
+    g1, g2 = H.g1_array(ps), H.g2_array(qs)
+    want = ctx.pairing_witness_batch(g1, g2)
+    monkeypatch.setenv("BLS381_WIT_GROUP", group)
+    assert np.array_equal(ctx.pairing_witness_batch(g1, g2), want)
+    monkeypatch.delenv("BLS381_WIT_GROUP")
+    assert np.array_equal(ctx.pairing_witness_batch(g1, g2), want)
+
+
 def test_pairing_witness_auxiliary_values(ctx):
     """The gadgets' auxiliary values beside the trace (mul quotients, add/sub/neg carry bytes, the inv row's quotient)
     against the CPU replay, which forms them from Python integers: a * b == q * p + r for every one of the 70,656

@@ -218,12 +218,17 @@ def test_witness_program_rows_match_circuit_op_totals():
     assert all(names[kinds[i]] == tr.rows[i][0] for i in range(len(kinds)))
 
 
-def test_witness_row_cache_plan_replays():
+@pytest.mark.parametrize("group", [None, "0", "8", "64"])
+def test_witness_row_cache_plan_replays(group, monkeypatch):
     """The witness kernel reads operand rows from a per-proof LDS cache wherever the host-made plan says the row
     is there.  Replaying the plan: every such read finds its row, no two results of one iteration share an entry,
-    the operations are otherwise those of the circuit replay, and the plan serves most reads at the default size."""
+    the operations are otherwise those of the circuit replay, and the plan serves most reads at the default size.
+    The replay also checks the level assignment under the plan (rows held back to fill groups of 16 by default, of
+    other sizes or not at all here): every row made exactly once, from rows of earlier levels."""
     import ctypes as C
     from plonky2_bls12_381_pairing_amd import _lib
+    if group is not None:
+        monkeypatch.setenv("BLS381_WIT_GROUP", group)
     out = (C.c_uint64 * 4)()
     reads = None
     for lpp, rows in ((16, 32), (16, 0), (16, 1), (16, 48), (8, 16), (32, 64), (64, 128), (1, 5)):
