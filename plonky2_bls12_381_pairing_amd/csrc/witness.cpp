@@ -543,12 +543,25 @@ __global__ __launch_bounds__(256) void witness_kernel(const WitnessOp* ops, cons
             w_load(T, ref, T, consts, in, x);
         }
     };
+    // A lane's operation is fetched one round ahead, before the round's results are stored: the wave's memory
+    // operations finish in order, so a fetch issued behind the stores would wait for them as well.
+    WitnessOp nxt = ops[0];
+    if (level_start[0] + sub < level_start[1]) nxt = ops[level_start[0] + sub];
     for (int l = 0; l < nlevels; l++) {
         const u32 lo = level_start[l], hi = level_start[l + 1];
-        for (u32 i = lo + sub; live && i < hi; i += lpp) {
-            const WitnessOp op = ops[i];
+        const u32 next_hi = level_start[l + 2 <= nlevels ? l + 2 : l + 1];
+        for (u32 base = lo; base < hi; base += lpp) {  // one round: the same trip count for every lane
+            const u32 i = base + sub;
+            const bool has = live && i < hi;
+            const WitnessOp op = nxt;
+            {
+                const bool same = base + lpp < hi;  // the next round is in this level, else the first of the next level
+                const u32 j = (same ? base + lpp : hi) + sub;
+                if (j < (same ? hi : next_hi)) nxt = ops[j];
+            }
             const u32 kind = op.dst >> 28, row = op.dst & WROW_MASK;
             u32 a[12], b[12], r[12];
+            if (has) {
             load(op.a, a);
             if (kind == WK_INV) {
                 // the only inv_nonnative on the path inverts the constant 2 (curves/g2.rs:149-151)
@@ -591,11 +604,12 @@ __global__ __launch_bounds__(256) void witness_kernel(const WitnessOp* ops, cons
             d[0] = make_uint4(r[0], r[1], r[2], r[3]);
             d[1] = make_uint4(r[4], r[5], r[6], r[7]);
             d[2] = make_uint4(r[8], r[9], r[10], r[11]);
+            }
             // (the compiler must not move this store above the reads of this iteration, nor the next iteration's
             // reads above it: other lanes of the wave read what this lane replaces)
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            if (op.dst & WCACHE_FLAG) {
+            if (has && (op.dst & WCACHE_FLAG)) {
                 uint4* q = cdata + (size_t)((op.dst >> WCACHE_SLOT_SHIFT) & WCACHE_SLOT_MASK) * 3;
                 q[0] = make_uint4(r[0], r[1], r[2], r[3]);
                 q[1] = make_uint4(r[4], r[5], r[6], r[7]);
