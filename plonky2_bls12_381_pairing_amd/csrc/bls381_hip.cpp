@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -1536,10 +1537,6 @@ extern "C" int bls381_debug_witness_cache_plan(int lanes_per_proof, int cache_ro
                         const uint32_t sl = (refs[k] >> WCACHE_SLOT_SHIFT) & WCACHE_SLOT_MASK;
                         if ((int)sl >= cache_rows || entry[sl] != (int64_t)(refs[k] & WROW_MASK)) out[2]++;
                     }
-                    if ((ops[j].dst & WROW_MASK) != (P.ops[ph][j].dst & WROW_MASK) || (ops[j].dst >> 28) != (P.ops[ph][j].dst >> 28) ||
-                        ((ops[j].a ^ P.ops[ph][j].a) & ~(WCACHE_FLAG | (WCACHE_SLOT_MASK << WCACHE_SLOT_SHIFT))) ||
-                        ((ops[j].b ^ P.ops[ph][j].b) & ~(WCACHE_FLAG | (WCACHE_SLOT_MASK << WCACHE_SLOT_SHIFT))))
-                        out[2]++;
                 }
                 std::vector<uint32_t> written;
                 for (uint32_t j = i; j < e; j++) {
@@ -1551,6 +1548,21 @@ extern "C" int bls381_debug_witness_cache_plan(int lanes_per_proof, int cache_ro
                 }
             }
         for (size_t m : made_in) if (m == NOT_MADE) out[2]++;
+        // apart from the cache fields, a level holds the operations the program holds for it (in any order)
+        const uint32_t plan_bits = WCACHE_FLAG | (WCACHE_SLOT_MASK << WCACHE_SLOT_SHIFT);
+        auto plain = [&](const WitnessOp& o) {
+            const bool ta = (o.a >> 30) == 0, tb = (o.b >> 30) == 0;
+            return std::array<uint32_t, 3>{o.dst & ~plan_bits, ta ? o.a & ~plan_bits : o.a, tb ? o.b & ~plan_bits : o.b};
+        };
+        if (ops.size() != P.ops[ph].size()) out[2]++;
+        else
+            for (size_t l = 0; l + 1 < ls.size(); l++) {
+                std::vector<std::array<uint32_t, 3>> x, y;
+                for (uint32_t j = ls[l]; j < ls[l + 1]; j++) { x.push_back(plain(ops[j])); y.push_back(plain(P.ops[ph][j])); }
+                std::sort(x.begin(), x.end());
+                std::sort(y.begin(), y.end());
+                if (x != y) out[2]++;
+            }
     }
     return 0;
 }

@@ -422,9 +422,8 @@ WitnessProgram build_program(int group) {
 // resident row whose next read lies furthest ahead (never one placed in the same iteration: two lanes would
 // write one entry).  Three operand reads in four then come from LDS at 32 rows, where a cache addressed by row
 // number holds one in three.  The operations come back with the cache fields of WitnessOp filled in.
-std::vector<WitnessOp> plan_row_cache(const WitnessProgram& P, int phase, int lpp, int cache_rows, size_t* reads_out,
-                                      size_t* hits_out) {
-    std::vector<WitnessOp> ops = P.ops[phase];
+static std::vector<WitnessOp> plan_in_order(const WitnessProgram& P, int phase, std::vector<WitnessOp> ops, int lpp, int cache_rows,
+                                            size_t* reads_out, size_t* hits_out) {
     const auto& ls = P.level_start[phase];
     size_t reads = 0, hits = 0;
     auto n_operands = [](const WitnessOp& o) { const uint32_t k = o.dst >> 28; return k == WK_NEG || k == WK_INV ? 1 : 2; };
@@ -486,6 +485,60 @@ std::vector<WitnessOp> plan_row_cache(const WitnessProgram& P, int phase, int lp
     if (reads_out) *reads_out = reads;
     if (hits_out) *hits_out = hits;
     return ops;
+}
+
+// The plan for the operations in the order the program holds them, then twice more with the operations of every
+// level reordered by what the plan before found: a wave waits for memory as soon as one of its 64 lanes reads a row
+// from the trace in global memory, so within a level (products first, as before) the operations with such a read
+// come together, and the groups of `lpp` after them read LDS only.  (The order within a level is free: its rows do
+// not depend on one another.)  BLS381_WIT_GATHER_MISSES=0 keeps the program's order.
+std::vector<WitnessOp> plan_row_cache(const WitnessProgram& P, int phase, int lpp, int cache_rows, size_t* reads_out,
+                                      size_t* hits_out) {
+    std::vector<WitnessOp> planned = plan_in_order(P, phase, P.ops[phase], lpp, cache_rows, reads_out, hits_out);
+    const auto& ls = P.level_start[phase];
+    auto stats = [&](const char* what) {  // groups of lpp operations in which no lane reads the trace in global memory
+        if (!getenv("BLS381_WIT_STATS")) return;
+        size_t groups = 0, quiet = 0;
+        for (size_t l = 0; l + 1 < ls.size(); l++)
+            for (uint32_t i = ls[l]; i < ls[l + 1]; i += (uint32_t)lpp) {
+                bool miss = false;
+                for (uint32_t j = i; j < std::min(i + (uint32_t)lpp, ls[l + 1]); j++) {
+                    const WitnessOp& o = planned[j];
+                    const uint32_t k = o.dst >> 28;
+                    miss |= (o.a >> 30) == 0 && !(o.a & WCACHE_FLAG);
+                    miss |= !(k == WK_NEG || k == WK_INV) && (o.b >> 30) == 0 && !(o.b & WCACHE_FLAG);
+                }
+                groups++; quiet += !miss;
+            }
+        fprintf(stderr, "witness phase %d plan (%s): %zu of %zu groups of %d read LDS only\n", phase, what, quiet, groups, lpp);
+    };
+    stats("program order");
+    const char* e = getenv("BLS381_WIT_GATHER_MISSES");
+    if (cache_rows == 0 || (e && atoi(e) == 0)) return planned;
+    const uint32_t plan_bits = WCACHE_FLAG | (WCACHE_SLOT_MASK << WCACHE_SLOT_SHIFT);
+    for (int pass = 0; pass < 2; pass++) {
+        auto class_of = [&](const WitnessOp& o) {  // 0: product reading the trace, 1: product, 2: other reading the trace, 3: other
+            const uint32_t k = o.dst >> 28;
+            const bool two = !(k == WK_NEG || k == WK_INV);
+            const bool miss = ((o.a >> 30) == 0 && !(o.a & WCACHE_FLAG)) || (two && (o.b >> 30) == 0 && !(o.b & WCACHE_FLAG));
+            return (k == WK_MUL ? 0 : 2) + (miss ? 0 : 1);
+        };
+        std::vector<WitnessOp> order;
+        order.reserve(planned.size());
+        for (size_t l = 0; l + 1 < ls.size(); l++)
+            for (int c = 0; c < 4; c++)
+                for (uint32_t j = ls[l]; j < ls[l + 1]; j++)
+                    if (class_of(planned[j]) == c) {
+                        WitnessOp o = planned[j];
+                        o.dst &= ~plan_bits;
+                        if ((o.a >> 30) == 0) o.a &= ~plan_bits;
+                        if ((o.b >> 30) == 0) o.b &= ~plan_bits;
+                        order.push_back(o);
+                    }
+        planned = plan_in_order(P, phase, std::move(order), lpp, cache_rows, reads_out, hits_out);
+        stats("reads of the trace gathered");
+    }
+    return planned;
 }
 
 const WitnessProgram& witness_program() {
