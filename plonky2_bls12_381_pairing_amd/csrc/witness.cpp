@@ -517,16 +517,19 @@ std::vector<WitnessOp> plan_row_cache(const WitnessProgram& P, int phase, int lp
     if (cache_rows == 0 || (e && atoi(e) == 0)) return planned;
     const uint32_t plan_bits = WCACHE_FLAG | (WCACHE_SLOT_MASK << WCACHE_SLOT_SHIFT);
     for (int pass = 0; pass < 2; pass++) {
-        auto class_of = [&](const WitnessOp& o) {  // 0: product reading the trace, 1: product, 2: other reading the trace, 3: other
+        // products first, then the other kinds one after the other (lanes of a group that hold different kinds run
+        // one kind after the other); within a kind, the operations that read the trace first
+        auto class_of = [&](const WitnessOp& o) {
             const uint32_t k = o.dst >> 28;
             const bool two = !(k == WK_NEG || k == WK_INV);
             const bool miss = ((o.a >> 30) == 0 && !(o.a & WCACHE_FLAG)) || (two && (o.b >> 30) == 0 && !(o.b & WCACHE_FLAG));
-            return (k == WK_MUL ? 0 : 2) + (miss ? 0 : 1);
+            const int rank = k == WK_MUL ? 0 : k == WK_ADD ? 1 : k == WK_SUB ? 2 : k == WK_NEG ? 3 : 4;
+            return rank * 2 + (miss ? 0 : 1);
         };
         std::vector<WitnessOp> order;
         order.reserve(planned.size());
         for (size_t l = 0; l + 1 < ls.size(); l++)
-            for (int c = 0; c < 4; c++)
+            for (int c = 0; c < 10; c++)
                 for (uint32_t j = ls[l]; j < ls[l + 1]; j++)
                     if (class_of(planned[j]) == c) {
                         WitnessOp o = planned[j];
