@@ -529,7 +529,8 @@ std::vector<WitnessOp> plan_row_cache(const WitnessProgram& P, int phase, int lp
         std::vector<WitnessOp> order;
         order.reserve(planned.size());
         for (size_t l = 0; l + 1 < ls.size(); l++)
-            for (int c = 0; c < 10; c++)
+            for (int c = 0; c < 10; c++) {
+                const size_t first = order.size();
                 for (uint32_t j = ls[l]; j < ls[l + 1]; j++)
                     if (class_of(planned[j]) == c) {
                         WitnessOp o = planned[j];
@@ -538,6 +539,9 @@ std::vector<WitnessOp> plan_row_cache(const WitnessProgram& P, int phase, int lp
                         if ((o.b >> 30) == 0) o.b &= ~plan_bits;
                         order.push_back(o);
                     }
+                // by row number within the class: neighbouring lanes then store neighbouring rows of the trace
+                std::sort(order.begin() + first, order.end(), [](const WitnessOp& x, const WitnessOp& y) { return (x.dst & WROW_MASK) < (y.dst & WROW_MASK); });
+            }
         planned = plan_in_order(P, phase, std::move(order), lpp, cache_rows, reads_out, hits_out);
         stats("reads of the trace gathered");
     }
