@@ -582,7 +582,9 @@ __device__ __forceinline__ void w_load(const u32* base, u32 ref, const u32* T, c
 // global memory, which always holds every finished row.  The lanes of a proof sit in one wave (lpp divides 64) and
 // a wave executes its LDS instructions in order, all lanes together: every lane's reads of an iteration precede
 // every lane's writes of it, as the plan assumes.
-__global__ __launch_bounds__(256) void witness_kernel(const WitnessOp* ops, const u32* level_start, int nlevels,
+// (Compiled for five waves per SIMD, 96 registers with two of them spilled: LDS then decides how many workgroups a
+// CU holds, 17 at the default 48 cache rows instead of the 16 that 112 registers allow; measured +2.5 %.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void witness_kernel(const WitnessOp* ops, const u32* level_start, int nlevels,
                                                       u32* trace, size_t rows, const u32* consts, const u32* inputs,
                                                       int lpp, int nproofs, int cache_rows) {
     extern __shared__ uint4 wcache[];
