@@ -582,8 +582,8 @@ __device__ __forceinline__ void w_load(const u32* base, u32 ref, const u32* T, c
 // global memory, which always holds every finished row.  The lanes of a proof sit in one wave (lpp divides 64) and
 // a wave executes its LDS instructions in order, all lanes together: every lane's reads of an iteration precede
 // every lane's writes of it, as the plan assumes.
-// (Compiled for five waves per SIMD, 96 registers with two of them spilled: LDS then decides how many workgroups a
-// CU holds, 17 at the default 48 cache rows instead of the 16 that 112 registers allow; measured +2.5 %.)
+// (Compiled for five waves per SIMD, 96 registers with two of them spilled, so that LDS and not the register file
+// decides how many workgroups a CU holds; measured +2.5 % at 48 cache rows against the 112-register build.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void witness_kernel(const WitnessOp* ops, const u32* level_start, int nlevels,
                                                       u32* trace, size_t rows, const u32* consts, const u32* inputs,
                                                       int lpp, int nproofs, int cache_rows) {
@@ -866,8 +866,11 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
     if (const char* e = getenv("BLS381_WIT_LPP")) lpp = atoi(e);
     // rows per proof kept in LDS, see witness_kernel and plan_row_cache (measured, proofs/s at 16 lanes per proof and
     // 16,384 proofs in flight: none 190 k, 16 rows 218 k, 32 rows 234 k, 48 rows 242 k, 64 rows 205 k: sixteen
-    // one-wave workgroups of four proofs per CU hold 144 KiB of LDS at 48 rows; more costs occupancy)
-    int cache_rows = 48;
+    // one-wave workgroups of four proofs per CU hold 144 KiB of LDS at 48 rows; more costs occupancy).  With the
+    // level assignment and the kernel at 96 registers: 48 rows 260-265 k, 52 rows 263-274 k, 53 rows 274-275 k: 53
+    // rows are the most that leave a CU its sixteen workgroups (16 x 4 x 53 x 48 bytes = 159 of 160 KiB), the
+    // 4,096 workgroups of a pass of 16,384 proofs then are all resident at once.
+    int cache_rows = 53;
     if (const char* e = getenv("BLS381_WIT_CACHE")) cache_rows = atoi(e);
     if (block < 1 || block > 256 || block % 64) { err = "BLS381_WIT_BLOCK must be 64, 128, 192 or 256"; return -1; }
     if (lpp < 1 || lpp > 64 || 64 % lpp) { err = "BLS381_WIT_LPP must divide 64"; return -1; }

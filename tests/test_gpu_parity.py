@@ -337,7 +337,7 @@ def test_pairing_witness_trace_256_proofs(ctx, CO, monkeypatch):
 @pytest.mark.parametrize("cache,lpp", [("0", "16"), ("16", "16"), ("1", "16"), ("48", "8"), ("100", "32"), ("128", "64")])
 def test_witness_kernel_geometries(ctx, cache, lpp, monkeypatch):
     """The witness kernel with no LDS row cache, one entry, small and large ones, at 8, 16, 32 and 64 lanes per proof
-    (each with its own cache plan): the same trace bytes as the default (32 rows, 16 lanes), which
+    (each with its own cache plan): the same trace bytes as the default (53 rows, 16 lanes), which
     test_pairing_witness_trace checks against the CPU replay."""
     ps, qs = H.random_pairs(5, 9191)
     g1, g2 = H.g1_array(ps), H.g2_array(qs)

@@ -231,7 +231,7 @@ def test_witness_row_cache_plan_replays(group, monkeypatch):
         monkeypatch.setenv("BLS381_WIT_GROUP", group)
     out = (C.c_uint64 * 4)()
     reads = None
-    for lpp, rows in ((16, 32), (16, 0), (16, 1), (16, 48), (8, 16), (32, 64), (64, 128), (1, 5)):
+    for lpp, rows in ((16, 32), (16, 0), (16, 1), (16, 48), (16, 53), (8, 16), (32, 64), (64, 128), (1, 5)):
         assert _lib.lib.bls381_debug_witness_cache_plan(lpp, rows, out) == 0
         assert out[2] == 0, (lpp, rows, list(out))
         assert out[3] == 141364
