@@ -6,7 +6,12 @@
  *
  * Data layouts (all little-endian):
  *   Fq    6 x u64, Montgomery form with R = 2^384: the in-memory limbs of ark_ff's Fq
- *         (BigInt<6>), so no conversion happens on either side.
+ *         (BigInt<6>), so no conversion happens on either side.  The limbs must be a canonical
+ *         residue (below p), as ark_ff's always are: a pairing, Miller-loop, final-exponentiation or
+ *         tower call (everything above the witness section below) that is handed a value >= p
+ *         returns BLS381_ERR_INVALID once its work has completed (outputs unspecified); the limbs
+ *         entry points report such values through their err bytes; the witness-trace calls reduce
+ *         their two input points mod p without a check.
  *   G1    {x, y}                      12 u64  (affine; infinity is carried by inf_flags)
  *   G2    {x.c0, x.c1, y.c0, y.c1}    24 u64
  *   Fq12  72 u64 in ark tower order   c0.c0.c0, c0.c0.c1, c0.c1.c0, ..., c1.c2.c1
@@ -211,8 +216,10 @@ int bls381_multi_ctx_verify_batch(bls381_multi_ctx*, const uint8_t* pk48, const 
  * then costs what every later one does.  No counterpart in the reference (host memory there is the allocator's). */
 int bls381_ctx_reserve(bls381_ctx*, size_t max_items);
 
-/* bls381_pairing_batch_dev for callers that cannot allocate device memory (code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same kernels and results as
+/* bls381_pairing_batch_dev for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc, code that must not disturb an allocator's state).  The call runs on the context's own stream and returns
+ * after synchronising it, so it is not itself capturable into a HIP graph: it serves the code around a capture that may
+ * not allocate.  No counterpart in the reference.  Same kernels and results as
  * bls381_pairing_batch_dev, but the workspace (slot arrays, carry and spill arrays) is a fixed 32 MiB array that
  * the library holds in each GPU's memory from load to process exit; the call makes no hipMalloc / hipFree.
  * n is at most BLS381_NOALLOC_MAX_PAIRS (larger n: BLS381_ERR_INVALID, nothing runs).  All calls on one GPU share

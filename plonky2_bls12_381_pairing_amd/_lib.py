@@ -21,6 +21,8 @@ if not os.path.exists(LIB_PATH):
 # (/opt/rocm), and the dynamic loader hands whichever was loaded first to every later user of that soname.  Torch on
 # the system's copy can fail to find its GPUs, so where torch is installed its copy is loaded first, whether or not
 # torch itself has been imported yet: this library and a later `import torch` then share it in either order.
+# (BLS381_NO_TORCH_RUNTIME=1 turns this off: the library then binds the runtime the dynamic loader finds.)
+PRELOADED_HIP_RUNTIME = None  # path of the libamdhip64.so this module loaded ahead of the library, if it did
 if "torch" not in sys.modules and os.environ.get("BLS381_NO_TORCH_RUNTIME") != "1":
     try:
         _spec = importlib.util.find_spec("torch")
@@ -28,10 +30,32 @@ if "torch" not in sys.modules and os.environ.get("BLS381_NO_TORCH_RUNTIME") != "
         _hip = os.path.join(_dirs[0], "lib", "libamdhip64.so") if _dirs else ""
         if _hip and os.path.exists(_hip):
             C.CDLL(_hip, mode=C.RTLD_GLOBAL)
+            PRELOADED_HIP_RUNTIME = _hip
     except (ImportError, OSError, ValueError):
         pass  # no torch, or its runtime does not load here: the system's runtime serves this library alone
 
 lib = C.CDLL(LIB_PATH)
+
+
+def hip_runtime_in_use():
+    """Paths of the libamdhip64 copies mapped into this process (one, when the loader above did its job) and the
+    version hipRuntimeGetVersion reports for the one the library is bound to (None if it cannot be asked)."""
+    paths = []
+    try:
+        with open("/proc/self/maps") as f:
+            paths = sorted({line.split()[-1] for line in f if "libamdhip64" in line})
+    except OSError:
+        pass
+    version = None
+    try:
+        rt = C.CDLL(paths[0]) if paths else None
+        if rt is not None:
+            v = C.c_int(0)
+            if rt.hipRuntimeGetVersion(C.byref(v)) == 0:
+                version = v.value
+    except (OSError, AttributeError):
+        pass
+    return {"paths": paths, "runtime_version": version, "preloaded": PRELOADED_HIP_RUNTIME}
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)

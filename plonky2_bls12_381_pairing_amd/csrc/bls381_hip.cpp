@@ -151,6 +151,10 @@ static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
 struct bls381_ctx {
     int device = 0;
     unsigned char* noalloc_scratch = nullptr;  // this device's copy of `scratch`
+    // One word of pinned host memory the layout-conversion kernel sets when an input value is not below p; d_bad is
+    // the device's address of the same word.  Cleared as a call starts, read after the call's last synchronisation.
+    unsigned* h_bad = nullptr;
+    unsigned* d_bad = nullptr;
     int K = 8;
     int lds_slots = 0;
     bool auto_geometry = false;  // defaults requested: per-program lane-group width
@@ -317,6 +321,10 @@ extern "C" int bls381_ctx_create_ex(bls381_ctx** out, int device_id, int K, int 
         rc = upload_program(c, nm);
         if (rc) return bail(rc);
     }
+    if (hipHostMalloc((void**)&c->h_bad, sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&c->d_bad, c->h_bad, 0) != hipSuccess)
+        return bail(fail(BLS381_ERR_HIP, "hipHostMalloc failed"));
+    *c->h_bad = 0;
     {
         void* sp = nullptr;
         hipError_t e = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
@@ -341,6 +349,7 @@ extern "C" void bls381_ctx_destroy(bls381_ctx* c) {
     if (c->d_consts) (void)hipFree(c->d_consts);
     if (c->d_vmconsts) (void)hipFree(c->d_vmconsts);
     if (c->d_trash) (void)hipFree(c->d_trash);
+    if (c->h_bad) (void)hipHostFree(c->h_bad);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->pipe_ev) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -424,7 +433,7 @@ static int pack(bls381_ctx* c, const void* aos_dev, void* soa, int n, int npad, 
     long total = (long)n * fp_per_elem;
     if (total == 0) return 0;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, (const u32*)aos_dev,
-                       (uint4*)soa, n, npad, fp_per_elem, slot0);
+                       (uint4*)soa, n, npad, fp_per_elem, slot0, c->d_bad);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -579,19 +588,31 @@ static int two_pairs_dev_locked(bls381_ctx* c, const uint64_t* g1a, const uint64
 #define CTX_GUARD(c)                                                     \
     if (!(c)) return fail(BLS381_ERR_INVALID, "ctx is NULL");            \
     std::lock_guard<std::mutex> lock_((c)->mu);                          \
-    HIPCHK(hipSetDevice((c)->device));
+    HIPCHK(hipSetDevice((c)->device));                                   \
+    *(c)->h_bad = 0;
+
+// The status of a call that took field elements in Montgomery form (6 x u64 per Fq): every such value passes through
+// pack_kernel, which notes one that is not below p.  ark_ff never holds such a value, but this is a C boundary: the
+// call is then refused as a whole (its outputs are unspecified), after its work has completed.
+static int checked(bls381_ctx* c, int rc) {
+    if (rc == 0 && *c->h_bad) {
+        *c->h_bad = 0;
+        return fail(BLS381_ERR_INVALID, "an input field element is not below p (Fq limbs must be canonical Montgomery residues)");
+    }
+    return rc;
+}
 
 extern "C" int bls381_pairing_batch_dev(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags,
                                         size_t n, uint64_t* out) {
     CTX_GUARD(c);
     if (n && (!g1 || !g2 || !out)) return fail(BLS381_ERR_INVALID, "NULL buffer");
-    return miller_dev_locked(c, g1, g2, flags, n, out, true);
+    return checked(c, miller_dev_locked(c, g1, g2, flags, n, out, true));
 }
 extern "C" int bls381_miller_loop_batch_dev(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags,
                                             size_t n, uint64_t* out) {
     CTX_GUARD(c);
     if (n && (!g1 || !g2 || !out)) return fail(BLS381_ERR_INVALID, "NULL buffer");
-    return miller_dev_locked(c, g1, g2, flags, n, out, false);
+    return checked(c, miller_dev_locked(c, g1, g2, flags, n, out, false));
 }
 
 // Grows the context's workspace now to what pairing / Miller-loop / final-exponentiation calls of up to max_items
@@ -615,7 +636,7 @@ extern "C" int bls381_ctx_reserve(bls381_ctx* c, size_t max_items) {
     return 0;
 }
 
-// bls381_pairing_batch_dev for callers that cannot allocate (code under graph capture, serving loops): the same
+// bls381_pairing_batch_dev for callers that cannot allocate (serving loops, harnesses that forbid hipMalloc): the same
 // kernels, their workspace carved out of this device's copy of `scratch` instead of the context's growing buffers.
 // Calls nothing that allocates; at most NOALLOC_MAX_PAIRS pairs; always the context's own lane-group width (the
 // 16-lane program variants of small batches are uploaded on first use, which allocates).
@@ -658,7 +679,7 @@ extern "C" int bls381_pairing_batch_dev_noalloc(bls381_ctx* c, const uint64_t* g
     if ((rc = run_program_on(c, "fe2", bC, bB, bT, m, npad))) return rc;
     if ((rc = unpack(c, bB, out, m, npad, 12, 0))) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return checked(c, 0);
 }
 
 // generic "n x in_fp Fp in -> program -> n x out_fp Fp out" on device pointers (up to 3 input arrays)
@@ -725,6 +746,7 @@ extern "C" int bls381_g2_prepared_create(bls381_ctx* c, const uint64_t* g2, int 
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
                 rc = fail(BLS381_ERR_HIP, "coefficient conversion failed");
         }
+        rc = checked(c, rc);
         if (rc) { if (h->d_consts) (void)hipFree(h->d_consts); delete h; return rc; }
     }
     *out = h;
@@ -842,7 +864,7 @@ static int final_exp_dev_locked(bls381_ctx* c, const uint64_t* in, size_t n, uin
 extern "C" int bls381_final_exp_batch_dev(bls381_ctx* c, const uint64_t* in, size_t n, uint64_t* out, uint8_t* zero_dev) {
     CTX_GUARD(c);
     if (n && (!in || !out)) return fail(BLS381_ERR_INVALID, "NULL buffer");
-    return final_exp_dev_locked(c, in, n, out, zero_dev, "fe2");
+    return checked(c, final_exp_dev_locked(c, in, n, out, zero_dev, "fe2"));
 }
 
 // ------------------------------------------------------------------ host-pointer entry points
@@ -954,12 +976,12 @@ static int fixed_q_host(bls381_ctx* c, const bls381_g2_prepared* q, const uint64
 extern "C" int bls381_miller_loop_fixed_q_batch(bls381_ctx* c, const bls381_g2_prepared* q, const uint64_t* g1,
                                                 const uint8_t* p_is_infinity, size_t n, uint64_t* out) {
     CTX_GUARD(c);
-    return fixed_q_host(c, q, g1, p_is_infinity, n, out, false);
+    return checked(c, fixed_q_host(c, q, g1, p_is_infinity, n, out, false));
 }
 extern "C" int bls381_pairing_fixed_q_batch(bls381_ctx* c, const bls381_g2_prepared* q, const uint64_t* g1,
                                             const uint8_t* p_is_infinity, size_t n, uint64_t* out) {
     CTX_GUARD(c);
-    return fixed_q_host(c, q, g1, p_is_infinity, n, out, true);
+    return checked(c, fixed_q_host(c, q, g1, p_is_infinity, n, out, true));
 }
 extern "C" int bls381_pairing_fixed_q_batch_dev(bls381_ctx* c, const bls381_g2_prepared* q, const uint64_t* g1,
                                                 const uint8_t* p_is_infinity, size_t n, uint64_t* out) {
@@ -967,18 +989,18 @@ extern "C" int bls381_pairing_fixed_q_batch_dev(bls381_ctx* c, const bls381_g2_p
     if (!q) return fail(BLS381_ERR_INVALID, "prepared point is NULL");
     if (q->device != c->device) return fail(BLS381_ERR_INVALID, "prepared point belongs to another device");
     if (n && (!g1 || !out)) return fail(BLS381_ERR_INVALID, "NULL buffer");
-    return fixed_q_dev_locked(c, q, g1, p_is_infinity, n, out, true);
+    return checked(c, fixed_q_dev_locked(c, q, g1, p_is_infinity, n, out, true));
 }
 
 extern "C" int bls381_miller_loop_batch(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags,
                                         size_t n, uint64_t* out) {
     CTX_GUARD(c);
-    return pairs_host(c, g1, g2, flags, n, out, false);
+    return checked(c, pairs_host(c, g1, g2, flags, n, out, false));
 }
 extern "C" int bls381_pairing_batch(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags, size_t n,
                                     uint64_t* out) {
     CTX_GUARD(c);
-    return pairs_host(c, g1, g2, flags, n, out, true);
+    return checked(c, pairs_host(c, g1, g2, flags, n, out, true));
 }
 
 static int two_pairs_host(bls381_ctx* c, const uint64_t* g1a, const uint64_t* g2a, const uint64_t* g1b, const uint64_t* g2b,
@@ -1019,20 +1041,20 @@ extern "C" int bls381_miller_loop_two_pairs_batch(bls381_ctx* c, const uint64_t*
                                                   const uint64_t* g2b, const uint8_t* flags, size_t n, uint64_t* out) {
     CTX_GUARD(c);
     if (n && !out) return fail(BLS381_ERR_INVALID, "NULL buffer");
-    return two_pairs_host(c, g1a, g2a, g1b, g2b, flags, n, out, nullptr, false);
+    return checked(c, two_pairs_host(c, g1a, g2a, g1b, g2b, flags, n, out, nullptr, false));
 }
 extern "C" int bls381_pairing_two_pairs_batch(bls381_ctx* c, const uint64_t* g1a, const uint64_t* g2a, const uint64_t* g1b,
                                               const uint64_t* g2b, const uint8_t* flags, size_t n, uint64_t* out,
                                               uint8_t* is_one) {
     CTX_GUARD(c);
-    return two_pairs_host(c, g1a, g2a, g1b, g2b, flags, n, out, is_one, true);
+    return checked(c, two_pairs_host(c, g1a, g2a, g1b, g2b, flags, n, out, is_one, true));
 }
 extern "C" int bls381_pairing_two_pairs_batch_dev(bls381_ctx* c, const uint64_t* g1a, const uint64_t* g2a, const uint64_t* g1b,
                                                   const uint64_t* g2b, const uint8_t* flags, size_t n, uint64_t* out,
                                                   uint8_t* is_one) {
     CTX_GUARD(c);
     if (n && (!g1a || !g2a || !g1b || !g2b || (!out && !is_one))) return fail(BLS381_ERR_INVALID, "NULL buffer");
-    return two_pairs_dev_locked(c, g1a, g2a, g1b, g2b, flags, n, out, is_one, true);
+    return checked(c, two_pairs_dev_locked(c, g1a, g2a, g1b, g2b, flags, n, out, is_one, true));
 }
 
 static int fe_host(bls381_ctx* c, const uint64_t* in, size_t n, uint64_t* out, uint8_t* zero, const char* part2) {
@@ -1054,11 +1076,11 @@ static int fe_host(bls381_ctx* c, const uint64_t* in, size_t n, uint64_t* out, u
 }
 extern "C" int bls381_final_exp_batch(bls381_ctx* c, const uint64_t* in, size_t n, uint64_t* out, uint8_t* zero) {
     CTX_GUARD(c);
-    return fe_host(c, in, n, out, zero, "fe2");
+    return checked(c, fe_host(c, in, n, out, zero, "fe2"));
 }
 extern "C" int bls381_easy_part_batch(bls381_ctx* c, const uint64_t* in, size_t n, uint64_t* out, uint8_t* zero) {
     CTX_GUARD(c);
-    return fe_host(c, in, n, out, zero, "easy2");
+    return checked(c, fe_host(c, in, n, out, zero, "easy2"));
 }
 
 static int simple_host(bls381_ctx* c, const char* prog, std::vector<InArr> ins, size_t n, void* out, int out_fp,
@@ -1082,16 +1104,16 @@ static int simple_host(bls381_ctx* c, const char* prog, std::vector<InArr> ins, 
 
 extern "C" int bls381_hard_part_batch(bls381_ctx* c, const uint64_t* in, size_t n, uint64_t* out) {
     CTX_GUARD(c);
-    return simple_host(c, "hardgen", {{in, 12}}, n, out, 12);
+    return checked(c, simple_host(c, "hardgen", {{in, 12}}, n, out, 12));
 }
 extern "C" int bls381_frobenius_batch(bls381_ctx* c, const uint64_t* in, unsigned power, size_t n, uint64_t* out) {
     CTX_GUARD(c);
     const std::string prog = "frob" + std::to_string(power % 12);  // the reference reduces the power mod 12
-    return simple_host(c, prog.c_str(), {{in, 12}}, n, out, 12);
+    return checked(c, simple_host(c, prog.c_str(), {{in, 12}}, n, out, 12));
 }
 extern "C" int bls381_conjugate_batch(bls381_ctx* c, const uint64_t* in, size_t n, uint64_t* out) {
     CTX_GUARD(c);
-    return simple_host(c, "conj", {{in, 12}}, n, out, 12);
+    return checked(c, simple_host(c, "conj", {{in, 12}}, n, out, 12));
 }
 extern "C" int bls381_pow_batch(bls381_ctx* c, const uint64_t* in, const uint64_t* exp, size_t exp_words, size_t n, uint64_t* out) {
     CTX_GUARD(c);
@@ -1110,7 +1132,7 @@ extern "C" int bls381_pow_batch(bls381_ctx* c, const uint64_t* in, const uint64_
                 if (it->first.rfind("pow:", 0) == 0) { (void)hipFree(it->second.d_blocks); it = c->progs.erase(it); } else ++it;
         }
     }
-    return simple_host(c, prog.c_str(), {{in, 12}}, n, out, 12);
+    return checked(c, simple_host(c, prog.c_str(), {{in, 12}}, n, out, 12));
 }
 extern "C" int bls381_pow_x_batch(bls381_ctx* c, const uint64_t* in, size_t n, uint64_t* out) {
     const uint64_t x = BLS381_X;
@@ -1118,16 +1140,16 @@ extern "C" int bls381_pow_x_batch(bls381_ctx* c, const uint64_t* in, size_t n, u
 }
 extern "C" int bls381_fq12_mul_batch(bls381_ctx* c, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
     CTX_GUARD(c);
-    return simple_host(c, "fq12mul", {{a, 12}, {b, 12}}, n, out, 12);
+    return checked(c, simple_host(c, "fq12mul", {{a, 12}, {b, 12}}, n, out, 12));
 }
 extern "C" int bls381_g2_prepare_batch(bls381_ctx* c, const uint64_t* g2, size_t n, uint64_t* out) {
     CTX_GUARD(c);
-    return simple_host(c, "g2prep", {{g2, 4}}, n, out, 68 * 6, 4096);
+    return checked(c, simple_host(c, "g2prep", {{g2, 4}}, n, out, 68 * 6, 4096));
 }
 extern "C" int bls381_ell_batch(bls381_ctx* c, const uint64_t* f, const uint64_t* coeffs, const uint64_t* g1, size_t n,
                                 uint64_t* out) {
     CTX_GUARD(c);
-    return simple_host(c, "ell", {{f, 12}, {coeffs, 6}, {g1, 2}}, n, out, 12);
+    return checked(c, simple_host(c, "ell", {{f, 12}, {coeffs, 6}, {g1, 2}}, n, out, 12));
 }
 
 // product of m Fq12 held in slots 0..11 of `src` (SoA, stride npad_src); result lands in c->bufB slots 0..11, element 0
@@ -1207,18 +1229,18 @@ static int multi_host(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, con
 extern "C" int bls381_multi_miller_loop(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags,
                                         size_t n, uint64_t out[72]) {
     CTX_GUARD(c);
-    return multi_host(c, g1, g2, flags, n, out, nullptr, false, false);
+    return checked(c, multi_host(c, g1, g2, flags, n, out, nullptr, false, false));
 }
 // a shard's share of a product that the caller exponentiates: off the exact Miller value by a factor in Fq
 static int multi_miller_loop_scaled(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags, size_t n,
                                     uint64_t out[72]) {
     CTX_GUARD(c);
-    return multi_host(c, g1, g2, flags, n, out, nullptr, false, true);
+    return checked(c, multi_host(c, g1, g2, flags, n, out, nullptr, false, true));
 }
 extern "C" int bls381_multi_pairing(bls381_ctx* c, const uint64_t* g1, const uint64_t* g2, const uint8_t* flags, size_t n,
                                     uint64_t out[72], int* is_one) {
     CTX_GUARD(c);
-    return multi_host(c, g1, g2, flags, n, out, is_one, true, true);
+    return checked(c, multi_host(c, g1, g2, flags, n, out, is_one, true, true));
 }
 extern "C" int bls381_finish_multi_pairing(bls381_ctx* c, const uint64_t* partials, size_t n, uint64_t out[72],
                                            int* is_one) {
@@ -1242,7 +1264,7 @@ extern "C" int bls381_finish_multi_pairing(bls381_ctx* c, const uint64_t* partia
         std::memcpy(one, BLS381_ONE_MONT, 48);
         *is_one = std::memcmp(out, one, sizeof one) == 0;
     }
-    return 0;
+    return checked(c, 0);
 }
 
 // ------------------------------------------------------------------ several GPUs behind one handle

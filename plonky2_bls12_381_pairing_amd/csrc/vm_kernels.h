@@ -484,8 +484,10 @@ __global__ __launch_bounds__(VM_THREADS) void vm_kernel(VmArgs A) {
 
 // ---- layout conversion: array-of-structures user buffers <-> slot arrays
 // aos: n elements of `fp_per_elem` Fp each (12 u32 per Fp); soa slots [slot0, slot0 + fp_per_elem)
+// `not_below_p` (may be null): set to 1 when some value read is not a canonical residue (limbs >= p): the programs
+// assume values below p at their inputs, and arkworks never holds anything else, but a C caller can.
 __global__ void pack_kernel(const u32* __restrict__ aos, uint4* __restrict__ soa, int n, int npad, int fp_per_elem,
-                            int slot0) {
+                            int slot0, unsigned* not_below_p) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (element, fp)
     long total = (long)n * fp_per_elem;
     if (i >= total) return;
@@ -493,7 +495,18 @@ __global__ void pack_kernel(const u32* __restrict__ aos, uint4* __restrict__ soa
     int f = (int)(i % fp_per_elem);
     const uint4* src = reinterpret_cast<const uint4*>(aos + i * 12);
     uint4* dst = soa + ((size_t)(slot0 + f) * 3) * npad + e;
-    dst[0] = src[0]; dst[npad] = src[1]; dst[2 * (size_t)npad] = src[2];
+    const uint4 v0 = src[0], v1 = src[1], v2 = src[2];
+    dst[0] = v0; dst[npad] = v1; dst[2 * (size_t)npad] = v2;
+    if (not_below_p) {
+        const u32 P[12] = BLS381_P_LIMBS;
+        u32 x[12];
+        unpack3(v0, v1, v2, x);
+        // x - p without keeping the difference: no borrow out of the top limb means x >= p
+        u32 borrow = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) (void)subb(x[k], P[k], borrow);
+        if (!borrow) *not_below_p = 1u;
+    }
 }
 __global__ void unpack_kernel(const uint4* __restrict__ soa, u32* __restrict__ aos, int n, int npad, int fp_per_elem,
                               int slot0) {

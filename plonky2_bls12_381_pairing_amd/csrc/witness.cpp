@@ -320,6 +320,8 @@ WitnessProgram build_program(int group) {
 
     P.group = group;
     P.n_rows = w.kinds.size();
+    // row references share their word with the row-cache fields: 18 bits of row number
+    if (P.n_rows > (size_t)WROW_MASK + 1) { P.error = "witness trace has more rows than an operand reference can name"; return P; }
     P.kinds = w.kinds;
     for (uint8_t kd : w.kinds) P.counts[kd]++;
     P.mul_index.assign(P.n_rows, 0xffffffffu);
@@ -385,7 +387,7 @@ WitnessProgram build_program(int group) {
                     pl.erase(pl.begin(), pl.begin() + take);
                 }
             }
-            if (!pool[0].empty() || !pool[1].empty()) { fprintf(stderr, "witness level assignment left rows over\n"); abort(); }
+            if (!pool[0].empty() || !pool[1].empty()) { P.error = "witness level assignment left rows over"; return P; }
         }
         P.level_start[phase].push_back(0);
         for (auto& rows : by) {
@@ -730,6 +732,12 @@ __global__ void witness_aux_kernel(const WitnessOp* ops, int nops, const u32* mu
     w_load(T, op.a, T, consts, in, a);
     w_load(T, WREF_ROW | row, T, consts, in, r);
     if (kind == WK_MUL || kind == WK_INV) {
+        // (the output's base pointer is what may be null, not an address derived from it)
+        u32* const qbase = kind == WK_MUL ? mul_quot : inv_quot;
+        if (!qbase) {
+            if (carry) carry[(size_t)proof * rows + row] = 0;
+            return;
+        }
         if (kind == WK_MUL) w_load(T, op.b, T, consts, in, b);
         else for (int k = 0; k < 12; k++) b[k] = r[k];  // a * a^-1
         u32 w[24];
@@ -760,8 +768,8 @@ __global__ void witness_aux_kernel(const WitnessOp* ops, int nops, const u32* mu
             }
             for (int k = i + 12; k < 24; k++) { w[k] = subb(w[k], (u32)c, bw); c = 0; }
         }
-        u32* dst = kind == WK_MUL ? mul_quot + ((size_t)proof * n_mul + mul_index[row]) * 24 : inv_quot + (size_t)proof * 24;
-        if (dst) for (int k = 0; k < 24; k++) dst[k] = q[k];
+        u32* dst = qbase + (kind == WK_MUL ? ((size_t)proof * n_mul + mul_index[row]) * 24 : (size_t)proof * 24);
+        for (int k = 0; k < 24; k++) dst[k] = q[k];
         if (carry) carry[(size_t)proof * rows + row] = 0;
         return;
     }
@@ -822,6 +830,7 @@ static hipError_t ensure(void*& p, size_t& have, size_t need) {
 int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint64_t* g1, const uint64_t* g2, size_t n,
                        uint32_t* trace, std::string& err, bool on_device, const WitnessAux* aux) {
     const WitnessProgram& P = witness_program();
+    if (!P.error.empty()) { err = P.error; return -1; }
     if (uploaded_ && prog_group_ != P.group) {  // another level assignment than the one uploaded
         WCHK(hipStreamSynchronize(stream));
         release();

@@ -52,6 +52,7 @@ struct WitnessProgram {
     std::vector<uint32_t> level_start[2]; // per phase, nlevels + 1 offsets into ops[phase]
     size_t counts[6] = {0, 0, 0, 0, 0, 0};
     std::vector<uint32_t> mul_index;      // per row: its ordinal among the mul rows (0xffffffff for other kinds)
+    std::string error;                    // non-empty: the program could not be built (WitnessDevice::run reports it)
 };
 // optional outputs beside the trace (any may be null): see bls381_pairing_witness_aux_batch
 struct WitnessAux {

@@ -465,19 +465,21 @@ class Context:
         check(lib.bls381_pairing_witness_batch(self._h, _p64(g1), _p64(g2), n, _p32(trace)))
         return trace
 
-    def pairing_witness_aux_batch(self, g1, g2):
+    def pairing_witness_aux_batch(self, g1, g2, want=(True, True, True)):
         """The trace plus the gadgets' auxiliary values: (trace, mul_quot (n, mul rows, 24), carry (n, rows),
-        inv_quot (n, 24))."""
+        inv_quot (n, 24)).  `want` says which of the three auxiliary outputs to ask for; the others are passed as
+        NULL, which the C ABI allows, and come back as None."""
         g1, g2 = _arr64(g1, 12), _arr64(g2, 24)
         n = g1.shape[0]
         if g2.shape[0] != n:
             raise ValueError("g1 and g2 must have one row per proof")
         rows, n_mul = lib.bls381_pairing_witness_rows(), lib.bls381_pairing_witness_mul_rows()
         trace = np.empty((n, rows, 12), dtype=np.uint32)
-        mq = np.empty((n, n_mul, 24), dtype=np.uint32)
-        cy = np.empty((n, rows), dtype=np.uint8)
-        iq = np.empty((n, 24), dtype=np.uint32)
-        check(lib.bls381_pairing_witness_aux_batch(self._h, _p64(g1), _p64(g2), n, _p32(trace), _p32(mq), _p8(cy), _p32(iq)))
+        mq = np.empty((n, n_mul, 24), dtype=np.uint32) if want[0] else None
+        cy = np.empty((n, rows), dtype=np.uint8) if want[1] else None
+        iq = np.empty((n, 24), dtype=np.uint32) if want[2] else None
+        check(lib.bls381_pairing_witness_aux_batch(self._h, _p64(g1), _p64(g2), n, _p32(trace), _p32(mq) if want[0] else None,
+                                                   _p8(cy) if want[1] else None, _p32(iq) if want[2] else None))
         return trace, mq, cy, iq
 
     # ---- measurement

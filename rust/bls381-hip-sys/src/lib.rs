@@ -53,7 +53,10 @@ extern "C" {
     pub fn bls381_pairing_witness_rows() -> usize;
     pub fn bls381_pairing_witness_kinds(kinds: *mut u8, capacity: usize) -> i32;
     pub fn bls381_pairing_witness_batch(ctx: *mut Bls381Ctx, g1: *const u64, g2: *const u64, n: usize, trace: *mut u32) -> i32;
-    pub fn bls381_pairing_witness_aux_batch(ctx: *mut Bls381Ctx, trace: *const u32, n: usize, mul_quot: *mut u32, carry: *mut u8, inv_quot: *mut u32) -> i32;
+    pub fn bls381_pairing_witness_batch_dev(ctx: *mut Bls381Ctx, g1: *const u64, g2: *const u64, n: usize, trace: *mut u32) -> i32;
+    pub fn bls381_pairing_witness_mul_rows() -> usize;
+    pub fn bls381_pairing_witness_aux_batch(ctx: *mut Bls381Ctx, g1: *const u64, g2: *const u64, n: usize, trace: *mut u32, mul_quot: *mut u32,
+                                            carry: *mut u8, inv_quot: *mut u32) -> i32;
 
     pub fn bls381_pairing_batch_dev(ctx: *mut Bls381Ctx, g1: *const u64, g2: *const u64, inf: *const u8, n: usize, out: *mut u64) -> i32;
     pub fn bls381_pairing_batch_dev_noalloc(ctx: *mut Bls381Ctx, g1: *const u64, g2: *const u64, inf: *const u8, n: usize, out: *mut u64) -> i32;
@@ -64,15 +67,21 @@ extern "C" {
     pub fn bls381_g2_prepared_destroy(h: *mut G2PreparedDev);
     pub fn bls381_miller_loop_fixed_q_batch(ctx: *mut Bls381Ctx, q: *const G2PreparedDev, g1: *const u64, p_inf: *const u8, n: usize, out: *mut u64) -> i32;
     pub fn bls381_pairing_fixed_q_batch(ctx: *mut Bls381Ctx, q: *const G2PreparedDev, g1: *const u64, p_inf: *const u8, n: usize, out: *mut u64) -> i32;
+    pub fn bls381_pairing_fixed_q_batch_dev(ctx: *mut Bls381Ctx, q: *const G2PreparedDev, g1: *const u64, p_inf: *const u8, n: usize, out: *mut u64) -> i32;
+    pub fn bls381_ctx_reserve(ctx: *mut Bls381Ctx, max_items: usize) -> i32;
 
     pub fn bls381_miller_loop_two_pairs_batch(ctx: *mut Bls381Ctx, g1a: *const u64, g2a: *const u64, g1b: *const u64, g2b: *const u64,
                                               inf: *const u8, n: usize, out: *mut u64) -> i32;
     pub fn bls381_pairing_two_pairs_batch(ctx: *mut Bls381Ctx, g1a: *const u64, g2a: *const u64, g1b: *const u64, g2b: *const u64,
                                           inf: *const u8, n: usize, out: *mut u64, is_one: *mut u8) -> i32;
+    pub fn bls381_pairing_two_pairs_batch_dev(ctx: *mut Bls381Ctx, g1a: *const u64, g2a: *const u64, g1b: *const u64, g2b: *const u64,
+                                              inf: *const u8, n: usize, out: *mut u64, is_one: *mut u8) -> i32;
     pub fn bls381_verify_batch(ctx: *mut Bls381Ctx, pk48: *const u8, msg96: *const u8, sig96: *const u8, n: usize, check_subgroup_mask: i32,
                                verdict: *mut u8, status: *mut u8) -> i32;
     pub fn bls381_fast_aggregate_verify(ctx: *mut Bls381Ctx, pk48: *const u8, n_keys: usize, msg96: *const u8, sig96: *const u8,
                                         check_subgroup_mask: i32, valid: *mut i32, key_status: *mut u8) -> i32;
+    pub fn bls381_fast_aggregate_verify_batch(ctx: *mut Bls381Ctx, pk48: *const u8, n_checks: usize, keys_per_check: usize, msg96: *const u8,
+                                              sig96: *const u8, check_subgroup_mask: i32, verdict: *mut u8, key_status: *mut u8) -> i32;
 
     pub fn bls381_g1_decompress_batch(ctx: *mut Bls381Ctx, in48: *const u8, n: usize, check_subgroup: i32, g1: *mut u64, status: *mut u8) -> i32;
     pub fn bls381_g2_decompress_batch(ctx: *mut Bls381Ctx, in96: *const u8, n: usize, check_subgroup: i32, g2: *mut u64, status: *mut u8) -> i32;
@@ -91,7 +100,13 @@ extern "C" {
     pub fn bls381_multi_ctx_destroy(m: *mut Bls381MultiCtx);
     pub fn bls381_multi_ctx_pairing_batch(m: *mut Bls381MultiCtx, g1: *const u64, g2: *const u64, inf: *const u8, n: usize, out: *mut u64) -> i32;
     pub fn bls381_multi_ctx_miller_loop_batch(m: *mut Bls381MultiCtx, g1: *const u64, g2: *const u64, inf: *const u8, n: usize, out: *mut u64) -> i32;
+    pub fn bls381_multi_ctx_devices(m: *const Bls381MultiCtx) -> i32;
+    pub fn bls381_multi_ctx_final_exp_batch(m: *mut Bls381MultiCtx, x: *const u64, n: usize, out: *mut u64, zero: *mut u8) -> i32;
+    pub fn bls381_multi_ctx_multi_miller_loop(m: *mut Bls381MultiCtx, g1: *const u64, g2: *const u64, inf: *const u8, n: usize, out: *mut u64) -> i32;
     pub fn bls381_multi_ctx_multi_pairing(m: *mut Bls381MultiCtx, g1: *const u64, g2: *const u64, inf: *const u8, n: usize, out: *mut u64, is_one: *mut i32) -> i32;
+    pub fn bls381_multi_ctx_pairing_witness_batch(m: *mut Bls381MultiCtx, g1: *const u64, g2: *const u64, n: usize, trace: *mut u32) -> i32;
+    pub fn bls381_multi_ctx_verify_batch(m: *mut Bls381MultiCtx, pk48: *const u8, msg96: *const u8, sig96: *const u8, n: usize,
+                                         check_subgroup_mask: i32, verdict: *mut u8, status: *mut u8) -> i32;
 }
 
 #[repr(C)]

@@ -145,6 +145,48 @@ def test_pow_native(ctx):
     assert np.array_equal(ctx.pow_native_batch(H.fq12_array(a), 0), H.fq12_array(a))
 
 
+def test_identities_the_reference_asserts_hold_on_the_gpu_path(ctx):
+    """Known answers that depend on no implementation, checked with the library's own entry points only (the
+    oracle supplies inputs, never expected values):
+      * the Frobenius map is the p-power map: frobenius_map_native(x, k) == x^(p^k), with the power taken by
+        pow_native(., p) applied k times (generic squarings, arbitrary x);
+      * easy_part_native(x) == x^((p^6 - 1)(p^2 + 1)), the reference's own fixed assertion
+        (/root/reference/src/native/final_exponentiation.rs:124-141), in the division-free form
+        easy(x) * x^(p^2) * x == x^(p^8) * x^(p^6);
+      * bilinearity with the exponent applied on the device: e([a]P, [b]Q) == e(P, Q)^(ab), and e(P, Q)^r == 1,
+        e(P, Q) != 1."""
+    xs = H.random_fq12(2, 4401)
+    x = H.fq12_array(xs)
+    p_words = [(R.P >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)]
+    powers = [x]
+    for k in range(1, 9):
+        powers.append(ctx.pow_native_batch(powers[-1], p_words))
+        if k <= 3 or k == 6:
+            assert np.array_equal(ctx.frobenius_map_batch(x, k), powers[k]), k
+    # x^(p^6) is the conjugate (the map of order two of Fq12 over Fq6)
+    assert np.array_equal(powers[6], ctx.conjugate_batch(x))
+    easy = ctx.easy_part_batch(x)
+    lhs = ctx.fq12_mul_batch(ctx.fq12_mul_batch(easy, powers[2]), x)
+    rhs = ctx.fq12_mul_batch(powers[8], powers[6])
+    assert np.array_equal(lhs, rhs)
+    # bilinearity
+    import random
+    rng = random.Random(4402)
+    ps, qs = H.random_pairs(3, 4403)
+    a = [rng.randrange(1, 1 << 64) for _ in range(3)]
+    b = [rng.randrange(1, 1 << 64) for _ in range(3)]
+    e_pq = ctx.pairing_batch(H.g1_array(ps), H.g2_array(qs))
+    e_ab = ctx.pairing_batch(H.g1_array([R.g1_mul(p, k) for p, k in zip(ps, a)]), H.g2_array([R.g2_mul(q, k) for q, k in zip(qs, b)]))
+    one = H.fq12_array([R.FQ12_ONE])[0]
+    r_words = [(R.R_ORDER >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+    for i in range(3):
+        ab = a[i] * b[i]
+        got = ctx.pow_native_batch(e_pq[i:i + 1], [ab & 0xFFFFFFFFFFFFFFFF, ab >> 64])
+        assert np.array_equal(got[0], e_ab[i]), i
+        assert not np.array_equal(e_pq[i], one)
+    assert all(np.array_equal(row, one) for row in ctx.pow_native_batch(e_pq, r_words))
+
+
 def test_g2_prepare_and_ell(ctx):
     ps, qs = H.random_pairs(3, 31)
     cf = ctx.g2_prepare_batch(H.g2_array(qs))
@@ -377,6 +419,23 @@ def test_pairing_witness_auxiliary_values(ctx):
         assert np.array_equal(cy[e], np.array(want_c, dtype=np.uint8))
         assert iq[e].tolist() == limbs24(want_i)
         assert 0 < cy[e].sum() < 141376 and not mq[e][:, 12:].any()      # quotients are below p
+
+
+def test_witness_auxiliary_outputs_may_be_null(ctx):
+    """include/bls381_hip.h lets any of the three auxiliary outputs be NULL: every subset gives the same bytes in the
+    outputs it does ask for as the call that asks for all three (and writes nowhere else: the trace is compared too)."""
+    ps, qs = H.random_pairs(2, 910)
+    g1, g2 = H.g1_array(ps), H.g2_array(qs)
+    full = ctx.pairing_witness_aux_batch(g1, g2)
+    for mask in range(7):
+        want = (bool(mask & 1), bool(mask & 2), bool(mask & 4))
+        got = ctx.pairing_witness_aux_batch(g1, g2, want)
+        assert np.array_equal(got[0], full[0]), mask
+        for k in range(3):
+            if want[k]:
+                assert np.array_equal(got[1 + k], full[1 + k]), (mask, k)
+            else:
+                assert got[1 + k] is None
 
 
 def test_fp_mul_kernel_against_big_integers(ctx):
@@ -1113,3 +1172,41 @@ def test_argument_errors_on_a_live_context(ctx):
     ps, qs = H.random_pairs(2, 31337)
     out = ctx.pairing_batch(H.g1_array(ps), H.g2_array(qs))
     assert H.fq12_from_row(out[1]) == R.native_pairing([ps[1]], [qs[1]])
+
+
+def test_field_elements_not_below_p_are_refused(ctx):
+    """The Montgomery-form entry points take the limbs ark_ff holds, which are always below p.  A C caller can pass
+    anything: a value with limbs >= p makes the whole call fail with BLS381_ERR_INVALID (the layout-conversion kernel
+    notes it), whichever input array holds it, on host and device pointers, and the context keeps working."""
+    import torch
+    import plonky2_bls12_381_pairing_amd as B
+    from plonky2_bls12_381_pairing_amd import _lib
+    ps, qs = H.random_pairs(4, 515)
+    g1, g2 = H.g1_array(ps), H.g2_array(qs)
+    good = ctx.pairing_batch(g1, g2)
+    p_limbs = np.array(R.fq_to_u64_limbs(R.P), dtype=np.uint64)
+    for which, col in (("g1", 6), ("g2", 18), ("g1", 0)):
+        b1, b2 = g1.copy(), g2.copy()
+        (b1 if which == "g1" else b2)[2, col:col + 6] = p_limbs           # exactly p: the smallest value that is refused
+        for fn in (ctx.pairing_batch, ctx.miller_loop_batch):
+            with pytest.raises(B.Bls381Error) as ei:
+                fn(b1, b2)
+            assert ei.value.code == -1 and "not below p" in str(ei.value)
+    b1 = g1.copy()
+    b1[3, 0:6] = np.uint64(0xFFFFFFFFFFFFFFFF)                            # all ones
+    d1 = torch.from_numpy(b1.view(np.int64)).cuda()
+    d2 = torch.from_numpy(g2.view(np.int64)).cuda()
+    out = torch.zeros((4, 72), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    assert _lib.lib.bls381_pairing_batch_dev(ctx.handle, d1.data_ptr(), d2.data_ptr(), None, 4, out.data_ptr()) == -1
+    assert b"not below p" in _lib.lib.bls381_last_error()
+    x = H.fq12_array(H.random_fq12(2, 516))
+    x[1, 66:72] = p_limbs
+    for fn in (ctx.final_exponentiation_batch, ctx.conjugate_batch, lambda v: ctx.fq12_mul_batch(v, v)):
+        with pytest.raises(B.Bls381Error):
+            fn(x)
+    # p - 1 is the largest value that passes, and the context is unharmed
+    pm1 = np.array(R.fq_to_u64_limbs(R.P - 1), dtype=np.uint64)
+    x[1, 66:72] = pm1
+    assert ctx.conjugate_batch(x).shape == (2, 72)
+    assert np.array_equal(ctx.pairing_batch(g1, g2), good)

@@ -281,3 +281,62 @@ def test_header_is_plain_c_and_the_c_example_links(tmp_path):
         out = subprocess.run(cmd + ["-I", os.path.join(root, "include"), str(src)], capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stderr[-800:]
     _build_c_example(tmp_path)
+
+
+def _c_prototypes(hdr):
+    """name -> (return kind, [parameter kinds]) of every function the header declares."""
+    text = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    text = re.sub(r"^\s*#.*$", " ", text, flags=re.M)
+
+    def kind(decl):
+        d = re.sub(r"\[[^\]]*\]", "*", decl.strip())          # uint64_t out[72] is a pointer parameter
+        ptr = d.count("*")
+        base = re.sub(r"\b(const|struct)\b|\*", " ", d).split()
+        if not base:
+            return None
+        t = base[0] if base[0] != "unsigned" else ("unsigned" if len(base) < 2 or base[1] not in ("int", "char") else "unsigned " + base[1])
+        t = {"uint64_t": "u64", "uint32_t": "u32", "uint8_t": "u8", "int": "i32", "unsigned": "u32", "unsigned int": "u32", "size_t": "usize",
+             "char": "c_char", "float": "f32", "double": "f64", "void": "void"}.get(t, "opaque:" + t)
+        return ("*" * ptr) + t
+    protos = {}
+    for ret, name, args in re.findall(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(bls381_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text):
+        if "typedef" in ret:
+            continue
+        params = [] if args.strip() in ("", "void") else [kind(a) for a in args.split(",")]
+        protos[name] = (kind(ret), params)
+    return protos
+
+
+def _rust_prototypes(src):
+    block = re.search(r'extern "C" \{(.*?)\n\}', src, flags=re.S).group(1)
+    block = re.sub(r"//.*", "", block)
+
+    def kind(t):
+        t = t.strip()
+        ptr = len(re.findall(r"\*(?:const|mut)", t))
+        base = re.sub(r"\*(?:const|mut)", " ", t).split()[-1]
+        base = {"Bls381Ctx": "opaque:bls381_ctx", "Bls381MultiCtx": "opaque:bls381_multi_ctx", "G2PreparedDev": "opaque:bls381_g2_prepared"}.get(base, base)
+        return ("*" * ptr) + base
+    protos = {}
+    for name, args, ret in re.findall(r"pub fn (bls381_[a-z0-9_]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", block):
+        params = [kind(a.split(":", 1)[1]) for a in args.split(",") if a.strip()]
+        protos[name] = (kind(ret) if ret.strip() else "void", params)
+    return protos
+
+
+def test_rust_ffi_declarations_match_the_header():
+    """No Rust toolchain here, so the extern block of rust/bls381-hip-sys cannot be compiled against the library:
+    every function it declares must exist in include/bls381_hip.h with the same parameters (count, order, pointer
+    depth, element type) and return type."""
+    hdr = _c_prototypes(open(os.path.join(ROOT, "include", "bls381_hip.h")).read())
+    rust = _rust_prototypes(open(os.path.join(ROOT, "rust", "bls381-hip-sys", "src", "lib.rs")).read())
+    assert len(hdr) > 60 and len(rust) > 50
+    for name, (ret, params) in rust.items():
+        assert name in hdr, name
+        c_ret, c_params = hdr[name]
+        assert ret == c_ret, (name, ret, c_ret)
+        assert params == c_params, (name, params, c_params)
+    # the entry points of the path itself are all bound
+    for name in ("bls381_pairing_batch", "bls381_multi_miller_loop", "bls381_final_exp_batch", "bls381_pairing_witness_batch",
+                 "bls381_pairing_witness_aux_batch", "bls381_fq12_inverse_limbs_batch", "bls381_g2_prepare_batch", "bls381_ell_batch"):
+        assert name in rust, name

@@ -58,6 +58,16 @@ def test_final_exponentiation_known_answers():
         R.final_exponentiation(R.FQ12_ZERO)
 
 
+def test_frobenius_is_the_p_power_map():
+    """frobenius_map_native(x, k) (src/native/fin_exp_helpers.rs:10-47) against its definition x -> x^(p^k) by plain
+    square-and-multiply: pins the tabulated constants and the w-power ordering without reference to any other code."""
+    x = H.random_fq12(1, 12)[0]
+    m = R.myfq12_from_fq12(x)
+    for k in (1, 2, 3):
+        assert R.myfq12_to_fq12(R.frobenius_map_native(m, k)) == R.fq12_pow(x, R.P ** k)
+    assert R.fq12_conj(x) == R.fq12_pow(x, R.P ** 6)
+
+
 def test_myfq12_roundtrip_and_mul():
     # src/utils/helpers.rs:248-267
     a, b = H.random_fq12(2, 3)

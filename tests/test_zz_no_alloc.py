@@ -45,3 +45,21 @@ def test_no_alloc_entry_point_matches_pairing_batch_dev():
         assert L.bls381_pairing_batch_dev_noalloc(ctx.handle, big1.data_ptr(), big2.data_ptr(), None, n, bout.data_ptr()) == -1
         assert b"at most 4096" in L.bls381_last_error()
         assert L.bls381_pairing_batch_dev_noalloc(ctx.handle, None, None, None, 0, None) == 0
+    # On a context that has run nothing yet (no workspace of its own to lean on; the kernels' code is on the device
+    # already, loaded by the calls above), with the driver's free-memory figure unchanged across the calls: the entry
+    # point exists for callers that may not allocate.
+    with B.Context(0) as fresh:
+        n = 64
+        g1, g2 = H.g1_array((ps * 4)[:n]), H.g2_array((qs * 4)[:n])
+        d1 = torch.from_numpy(g1.view(np.int64)).cuda()
+        d2 = torch.from_numpy(g2.view(np.int64)).cuda()
+        got = torch.full((n, 72), -1, dtype=torch.int64, device="cuda")
+        want = torch.zeros((n, 72), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        for _ in range(2):
+            _lib.check(L.bls381_pairing_batch_dev_noalloc(fresh.handle, d1.data_ptr(), d2.data_ptr(), None, n, got.data_ptr()))
+        assert torch.cuda.mem_get_info()[0] == free_before
+        _lib.check(L.bls381_pairing_batch_dev(fresh.handle, d1.data_ptr(), d2.data_ptr(), None, n, want.data_ptr()))
+        assert torch.equal(got, want)
+        assert np.array_equal(got[:16].cpu().numpy().view(np.uint64), H.fq12_array([H.R.native_pairing([p], [q]) for p, q in zip(ps, qs)]))
