@@ -10,6 +10,18 @@ the process group is only used for the timing barrier and the MAX reduction of t
 Prints ONE JSON line on rank 0 with the fields the driver expects plus
   roofline      dominant kernel (final exponentiation part 2) against the v_mad_u64_u32 issue rate
   cpu_baseline  the C restatement of the reference's native path (oracle/c) on the host cores
+  verified_outputs   how many of the step's 65,536 outputs were compared with the CPU oracle's (every pairing the
+                     baseline leg computes is compared, none is thrown away)
+and, outside the timed region (rank 0, one GPU; --no-extras leaves them out), the other configured workloads:
+  multi_pairing_513  the 512-key aggregate check (513 pairs -> one Fq12 -> final exponentiation -> is one), valid and
+                     forged, latency per call
+  shard_1m           one GPU's shard of the 8,388,608-pair configuration: 1,048,576 pairings on device pointers
+  witness            the pairing circuit's witness trace: 256 proofs through host pointers and 16,384 proofs left in
+                     HBM, proofs/s, fractions of the multiply-accumulate and HBM rooflines, every row of one proof
+                     against the CPU replay of the circuit
+With N > 1 ranks (or BLS381_BENCH_FORCE_DIST=1) the 513-pair product is also run sharded over the ranks: each rank
+reduces its share to one Fq12, the partials are all-gathered through the process group (RCCL over xGMI) and every
+rank finishes and checks the result (multi_pairing_rccl).
 """
 import argparse
 import ctypes as C
@@ -27,6 +39,12 @@ BATCH = 65536
 # Algorithmic work: Fp-multiplication-equivalents of the reference's formulas x 300 multiply-accumulates
 # (12 x 32-bit limbs: 144 for the product, 156 for the Montgomery reduction)
 W_PAIR = 15260 * 300          # whole pairing
+# what a pairing call executes of that model: its Miller loop runs the G2 doublings without their halvings, four
+# multiplications fewer in each of the 63 doublings (same pairing values)
+W_PAIR_EXECUTED = (15260 - 63 * 4) * 300
+W_WITNESS = 70656 * 300       # the trace's mul rows
+WITNESS_BYTES = 141364 * 48   # bytes of trace rows written per proof (operation rows)
+PEAK_HBM = 8e12
 W_MILLER = 7141 * 300         # G2 line precompute + Miller loop
 W_FE2 = (8119 - 460 - 75) * 300   # final exponentiation minus the Fp inversion chain and the norm part
 PEAK_MAC = 256 * 4 * 64 / 4 * 2.4e9   # v_mad_u64_u32: 4 cycles per wave64 instruction per SIMD (measured), 2.4 GHz
@@ -44,6 +62,115 @@ def synth_inputs(np, H, n):
     return g1b[i % m], g2b[(i // m) % m], g1b, g2b
 
 
+def aggregate_check_inputs(H):
+    """512 (public key, message point) pairs and (-G1, signature): the product of the 513 pairings is one.  Eight
+    distinct keys and message points, tiled.  Returns g1 (513, 12), g2 (513, 24), and g2 with a forged signature."""
+    import random
+    R = H.R
+    rng = random.Random(512)
+    n, base = 512, 8
+    sks = [rng.randrange(1, R.R_ORDER) for _ in range(base)]
+    hs = [rng.randrange(1, R.R_ORDER) for _ in range(base)]
+    pks = [R.g1_mul(R.G1_GEN, s) for s in sks]
+    Hs = [R.g2_mul(R.G2_GEN, h) for h in hs]
+    ps = [pks[i % base] for i in range(n)] + [R.g1_neg(R.G1_GEN)]
+    qs = [Hs[i % base] for i in range(n)]
+    sigma = sum(sks[i % base] * hs[i % base] for i in range(n)) % R.R_ORDER
+    good = qs + [R.g2_mul(R.G2_GEN, sigma)]
+    forged = qs + [R.g2_mul(R.G2_GEN, (sigma + 1) % R.R_ORDER)]
+    return H.g1_array(ps), H.g2_array(good), H.g2_array(forged)
+
+
+def bench_multi_pairing(np, H, ctx):
+    g1, g2, g2_forged = aggregate_check_inputs(H)
+    e, one = ctx.native_pairing(g1, g2)
+    _, one_forged = ctx.native_pairing(g1, g2_forged)
+    if not one or one_forged or not np.array_equal(e, H.fq12_array([H.R.FQ12_ONE])[0]):
+        raise SystemExit("the 513-pair aggregate check gives the wrong verdict")
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.native_pairing(g1, g2)
+    return {"pairs": 513, "ms_per_check": (time.perf_counter() - t0) / reps * 1e3, "is_one": True, "forged_is_one": False,
+            "what": "bls381_multi_pairing on host pointers: 513 Miller loops, in-kernel product tree, one final exponentiation"}
+
+
+def bench_shard(np, torch, _lib, ctx, dev, g1, g2, d_out_batch):
+    """1,048,576 pairings on device pointers: the 65,536 verified pairs of the timed step, sixteen times over."""
+    n = 1 << 20
+    reps = n // BATCH
+    d1 = torch.from_numpy(np.tile(g1, (reps, 1)).view(np.int64)).to(dev)
+    d2 = torch.from_numpy(np.tile(g2, (reps, 1)).view(np.int64)).to(dev)
+    out = torch.empty((n, 72), dtype=torch.int64, device=dev)
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _lib.check(_lib.lib.bls381_pairing_batch_dev(ctx.handle, d1.data_ptr(), d2.data_ptr(), None, n, out.data_ptr()))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    same = all(bool(torch.equal(out[k * BATCH:(k + 1) * BATCH], d_out_batch)) for k in range(reps))
+    if not same:
+        raise SystemExit("the 1,048,576-pair shard differs from the verified 65,536-pair batch it repeats")
+    return {"pairings": n, "ms": best * 1e3, "pairings_per_s": n / best, "whole_step_frac": n / best * W_PAIR_EXECUTED / PEAK_MAC,
+            "outputs_equal_to_the_verified_batch": n}
+
+
+def bench_witness(np, torch, _lib, H, B, ctx, dev):
+    import witness_ref as W
+    R = H.R
+    ps, qs = H.random_pairs(8, 31)
+    a, b = H.g1_array(ps), H.g2_array(qs)
+    rows = B.witness_rows()
+    # every row of proof 0 from the CPU replay of the circuit's builder calls
+    tr, _ = W.pairing_witness(ps[0], qs[0])
+    want = np.array([R.fq_to_u32_limbs(v) for _, v in tr.rows], dtype=np.uint32)
+    res = {"rows_per_proof": rows, "bytes_per_proof": rows * 48}
+    # host pointers, the configured 256 proofs (the copy of 6.79 MB per proof back to the host is most of it)
+    n = 256
+    g1, g2 = np.tile(a, (n // 8, 1)), np.tile(b, (n // 8, 1))
+    ctx.pairing_witness_batch(g1[:8], g2[:8])
+    t0 = time.perf_counter()
+    trace = ctx.pairing_witness_batch(g1, g2)
+    dt = time.perf_counter() - t0
+    if not (np.array_equal(trace[0], want) and np.array_equal(trace[8], want)):
+        raise SystemExit("witness trace (host form) differs from the CPU replay of the circuit")
+    res["host_256"] = {"proofs": n, "ms": dt * 1e3, "proofs_per_s": n / dt, "rows_compared_with_cpu_replay": 2 * rows}
+    del trace
+    # the trace left in HBM: 16,384 proofs in one pass
+    n = 16384
+    free = torch.cuda.mem_get_info()[0]
+    while n > 1024 and n * rows * 48 > 0.8 * free:
+        n //= 2
+    d1 = torch.from_numpy(np.tile(a, (n // 8, 1)).view(np.int64)).to(dev)
+    d2 = torch.from_numpy(np.tile(b, (n // 8, 1)).view(np.int64)).to(dev)
+    d_trace = torch.empty((n, rows, 12), dtype=torch.int32, device=dev)
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _lib.check(_lib.lib.bls381_pairing_witness_batch_dev(ctx.handle, d1.data_ptr(), d2.data_ptr(), n, d_trace.data_ptr()))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    first = d_trace[0].cpu().numpy().view(np.uint32)
+    last = d_trace[n - 8].cpu().numpy().view(np.uint32)
+    if not (np.array_equal(first, want) and np.array_equal(last, want)):
+        raise SystemExit("witness trace (device form) differs from the CPU replay of the circuit")
+    # a checksum over all proofs: every group of eight proofs repeats the first eight
+    groups = d_trace.view(n // 8, 8 * rows * 12)
+    sums = torch.cat([groups[k:k + 32].sum(dim=1, dtype=torch.int64) for k in range(0, n // 8, 32)])   # (in slices: the widened copy stays small)
+    if not bool((sums == sums[0]).all()):
+        raise SystemExit("witness trace checksums differ between identical proofs")
+    rate = n / best
+    res["device_%d" % n] = {"proofs": n, "ms": best * 1e3, "proofs_per_s": rate,
+                            "mac_roofline_frac": rate * W_WITNESS / PEAK_MAC, "hbm_roofline_frac": rate * WITNESS_BYTES / PEAK_HBM,
+                            "trace_GB_per_s_written": rate * rows * 48 / 1e9, "rows_compared_with_cpu_replay": 2 * rows,
+                            "checksum_groups_equal": n // 8}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -52,6 +179,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per pairing (0 = library default)")
     ap.add_argument("--lds-slots", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="leave out the workloads measured outside the timed region")
     args = ap.parse_args()
 
     import numpy as np
@@ -76,6 +204,9 @@ def main():
     # code path (initialisation, barrier, device-tensor all-reduce and all-gather) the multi-GPU launch will take
     if world > 1 or os.environ.get("BLS381_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
+        if world == 1:  # (a forced one-rank group started without a launcher: rendezvous with itself)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
         else:
@@ -119,6 +250,38 @@ def main():
     ref = CO.pairing_batch(g1[sample], g2[sample])
     if not np.array_equal(out[sample], ref):
         raise SystemExit("rank %d: GPU pairings differ from the CPU oracle" % rank)
+    verified = set(int(i) for i in sample)
+
+    # The 513-pair product (512 keys and their message points, and the signature against -G1) sharded over the ranks:
+    # each rank reduces its share to one Fq12 on its GPU, one all-gather of 72 u64 per rank, every rank multiplies the
+    # partials out, runs the one final exponentiation and compares with the same check done on its GPU alone.
+    rccl = None
+    if dist is not None:
+        from plonky2_bls12_381_pairing_amd.parallel import all_gather_partials, shard_range
+        mg1, mg2, mg2_forged = aggregate_check_inputs(H)
+        alone, alone_one = ctx.native_pairing(mg1, mg2)
+        lo, hi = shard_range(len(mg1), rank, world)
+        gdev = dev if backend == "nccl" else None
+
+        def sharded(q):
+            part = ctx.multi_miller_loop_native(mg1[lo:hi], q[lo:hi])
+            return ctx.finish_multi_pairing(all_gather_partials(part, device=gdev))
+        e, one = sharded(mg2)
+        e_forged, one_forged = sharded(mg2_forged)
+        ok = bool(one) and bool(alone_one) and np.array_equal(e, alone) and not one_forged
+        barrier()
+        t1 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            sharded(mg2)
+        barrier()
+        t_sh = torch.tensor([(time.perf_counter() - t1) / reps, 0.0 if ok else 1.0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t_sh, op=dist.ReduceOp.MAX)
+        if float(t_sh[1].item()) != 0.0:
+            raise SystemExit("rank %d: the sharded 513-pair product differs from the one-GPU result" % rank)
+        rccl = {"pairs": len(mg1), "ranks": world, "backend": backend, "ms_per_check": float(t_sh[0].item()) * 1e3,
+                "is_one": bool(one), "forged_is_one": bool(one_forged), "equals_one_gpu_result": True,
+                "exchange": "all_gather of one 576-byte Fq12 partial product per rank, then bls381_finish_multi_pairing on every rank"}
 
     # which ranks took part: every rank contributes its number through the process group
     ranks_seen = [0]
@@ -176,10 +339,15 @@ def main():
                 "peak_measured": peak_measured / 1e12,
                 "peak_measured_clock_GHz": calib_clock_ghz,
                 "frac_of_measured_peak": achieved / peak_measured,
-                "whole_step_frac": value / world * W_PAIR / PEAK_MAC,
+                "whole_step_frac": value / world * W_PAIR_EXECUTED / PEAK_MAC,
+                "whole_step_work": "%d multiply-accumulates per pairing: the reference's 15,260 Fp multiplications less the 4 "
+                                   "per G2 doubling that pairing calls leave out, x 300" % W_PAIR_EXECUTED,
                 "kernel_ms": {"miller": ms_miller, "fe1_plus_inversion": ms_fe1, "fe2": ms_fe2},
             },
         }
+        if rccl is not None:
+            res["multi_pairing_rccl"] = rccl
+        res["hip_runtime"] = _lib.hip_runtime_in_use()
         if world == 1 and not args.no_cpu_baseline:
             # every core this process may use: its affinity mask, or what the box grants through OMP_NUM_THREADS
             # (a one-GPU share of a larger host); the machine's total is stated beside it
@@ -195,15 +363,21 @@ def main():
             nsamp = int(min(BATCH, max(len(probe), rate * 22.0)))   # 10-20 s of CPU work (the cold probe reads low)
             idx = np.arange(nsamp) * 37 % BATCH
             t1 = time.perf_counter()
-            CO.pairing_batch(g1[idx], g2[idx])
+            cpu_out = CO.pairing_batch(g1[idx], g2[idx])
             dt = time.perf_counter() - t1
             # second row: the same work with an optimised final exponentiation (cyclotomic squarings), so that
             # the reference's slow MyFq12 products do not inflate the ratio
             CO.set_fast(True)
             t2 = time.perf_counter()
-            CO.pairing_batch(g1[idx], g2[idx])
+            cpu_out_fast = CO.pairing_batch(g1[idx], g2[idx])
             dt_fast = time.perf_counter() - t2
             CO.set_fast(False)
+            # every pairing the baseline computed is also a check of the GPU's output for the same pair
+            if not (np.array_equal(out[idx], cpu_out) and np.array_equal(cpu_out_fast, cpu_out)):
+                bad = np.nonzero((out[idx] != cpu_out).any(axis=1))[0]
+                raise SystemExit("GPU pairings differ from the CPU oracle at %d of %d compared outputs (first: %s)" %
+                                 (len(bad), nsamp, idx[bad[:4]].tolist()))
+            verified.update(int(i) for i in idx)
             # third figure: the reference's algorithm on one host thread (a short sample: about 2 s)
             CO.set_threads(1)
             n_one = int(min(nsamp, max(16, nsamp / dt / cores * 2.0)))
@@ -226,6 +400,13 @@ def main():
                           "144-multiplication MyFq12 final exponentiation; Frobenius constants precomputed), "
                           "OpenMP over %d host threads, %.1f s" % (nsamp, cores, dt),
             }
+        res["verified_outputs"] = {"compared": len(verified), "of": BATCH, "against": "CPU oracle (C restatement of the reference), bit for bit"}
+        if world == 1 and not args.no_extras:
+            t_extra = time.perf_counter()
+            res["multi_pairing_513"] = bench_multi_pairing(np, H, ctx)
+            res["shard_1m"] = bench_shard(np, torch, _lib, ctx, dev, g1, g2, d_out)
+            res["witness"] = bench_witness(np, torch, _lib, H, B, ctx, dev)
+            res["extras_s"] = time.perf_counter() - t_extra
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()
