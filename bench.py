@@ -182,6 +182,12 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="leave out the workloads measured outside the timed region")
     args = ap.parse_args()
 
+    # The JSON line is the only thing this program writes to its standard output: native libraries (RCCL prints a
+    # version banner when a process group comes up) get the standard error stream instead.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import helpers as H
@@ -407,7 +413,8 @@ def main():
             res["shard_1m"] = bench_shard(np, torch, _lib, ctx, dev, g1, g2, d_out)
             res["witness"] = bench_witness(np, torch, _lib, H, B, ctx, dev)
             res["extras_s"] = time.perf_counter() - t_extra
-        print(json.dumps(res))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
