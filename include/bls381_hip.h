@@ -231,7 +231,7 @@ int bls381_pairing_batch_dev_noalloc(bls381_ctx*, const uint64_t* g1_dev, const 
                                      const uint8_t* inf_flags_dev, size_t n, uint64_t* out_fq12_dev);
 
 /* Introspection used by the tests and the benchmark. */
-/* Builds and schedules the step program `which` ("miller", "millerfq", "miller2", "fe1", "fe2", "g2prep", "ell", "fq12mul",
+/* Builds and schedules the step program `which` ("miller", "millerfq", "miller2", "fe1", "fe2", "fe2s0" .. "fe2s5", "g2prep", "ell", "fq12mul",
  * "easy2", "hardgen", "inv1", "inv2", "conj", "frob0" .. "frob11", "pow:<16 hex digits per exponent word>") for groups of K lanes and copies it into
  * caller buffers: hdrs = nsteps x 2 u32, descs = nsteps x K x 12 u32.  info[8] receives
  * {K, nsteps, lds_slots, tmp_slots, n_in, n_out, multiply-accumulates executed (300 per product, 444 per two-product sum), n_lin}.  Pass NULL buffers to query sizes.
@@ -248,6 +248,19 @@ int bls381_debug_fp_mul(bls381_ctx*, const uint32_t* a, const uint32_t* b, size_
  * Fq12::inverse (/root/reference/src/native/final_exponentiation.rs:9, through ark-ff) bottoms out
  * in, exposed for direct testing. */
 int bls381_debug_fp_inverse(bls381_ctx*, const uint32_t* a, size_t n, uint32_t* out, uint8_t* is_zero);
+/* The squaring chains of the hard part (/root/reference/src/native/final_exponentiation.rs:44-72 calls pow_native five
+ * times, /root/reference/src/native/fin_exp_helpers.rs:60-82: 63 squarings each) run as a kernel of their own that keeps
+ * a^(2^k) for the set bits k of |x| = 0xd201000000010000 (16, 48, 57, 60, 62, 63): this runs it alone on n <= 65,536
+ * values of the cyclotomic subgroup.  in: n x 12 Fq (ark tower order) as 12 x u32 canonical words carrying the
+ * Montgomery factor 2^392 (the kernels' internal factor; not the 2^384 of the entry points above), out: n x 6 x 12 Fq in
+ * the same form, the kept powers in ascending order of k.  bls381_last_timing()[2] then holds the kernel's time. */
+int bls381_debug_cyc_chain(bls381_ctx*, const uint32_t* in, size_t n, uint32_t* out);
+/* Pairing and final-exponentiation calls of more than 8,192 items run the second part of the final exponentiation as
+ * six step programs with that kernel between them (BLS381_FE2_CHAIN=0 in the environment keeps the single program,
+ * =1 takes the chained form for every size; same values either way).  After such a call: ms[0] = its five chain
+ * launches together, ms[1] = its six programs together (last 65,536-item chunk), *used = 1; *used = 0 if the single
+ * program ran. */
+int bls381_last_chain_timing(bls381_ctx*, float ms[2], int* used);
 /* The witness kernel keeps `cache_rows` (0..128) trace rows per proof in LDS, filled and read according to a plan
  * made on the host for the number of lanes that serve one proof (a divisor of 64).  Builds that plan and replays it:
  * out = {operand reads of trace rows, reads the plan serves from LDS, plan violations (must be 0), operations}.

@@ -20,6 +20,7 @@
 #include "generators.h"
 #include "points.h"
 #include "witness.h"
+#include "cyc_chain_host.h"
 
 using namespace bls381;
 
@@ -63,6 +64,7 @@ static Dag build_named(const std::string& which, int K) {
     if (which == "ell") return build_ell();
     if (which == "fe1") return build_final_exp_part1();
     if (which == "fe2") return build_final_exp_part2(true);
+    if (which.size() == 5 && which.rfind("fe2s", 0) == 0 && which[4] >= '0' && which[4] <= '5') return build_final_exp_chain_part(which[4] - '0');
     if (which == "easy2") return build_easy_part2();
     if (which == "hardgen") return build_hard_part_generic();
     if (which == "inv1") return build_fq12_inv_limbs_part1();
@@ -169,7 +171,10 @@ struct bls381_ctx {
     uint4* d_trash = nullptr;  // VmArgs::trash
     unsigned long long* d_prof = nullptr;  // set while bls381_debug_profile runs
     const uint4* consts_override = nullptr;  // set while a program runs against a prepared G2 point's table
-    DevBuf user_in, user_in2, user_in3, user_in4, user_out, flags, bufA, bufB, bufC, bufD, bufE, bufTmp, zflags, ilist;
+    DevBuf user_in, user_in2, user_in3, user_in4, user_out, flags, bufA, bufB, bufC, bufD, bufE, bufF, bufTmp, zflags, ilist;
+    hipEvent_t ev_chain[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool chain_timed = false;        // the last final exponentiation went through the squaring-chain kernel
+    float last_chain_ms[2] = {0, 0};  // its five chain launches together, its six programs together
     const int* n_dev_override = nullptr;  // set while a program runs over a count that lives on the device
     DevBuf vbuf[8];  // stages of the signature check from bytes
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -308,6 +313,7 @@ extern "C" int bls381_ctx_create_ex(bls381_ctx** out, int device_id, int K, int 
         hipStreamCreate(&c->aux_stream) != hipSuccess)
         return bail(fail(BLS381_ERR_HIP, "hipStreamCreate failed"));
     for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) return bail(fail(BLS381_ERR_HIP, "hipEventCreate failed"));
+    for (auto& e : c->ev_chain) if (hipEventCreate(&e) != hipSuccess) return bail(fail(BLS381_ERR_HIP, "hipEventCreate failed"));
     std::vector<uint32_t> consts, vmc;
     fill_constants(consts);
     fill_vm_constants(vmc);
@@ -342,7 +348,7 @@ extern "C" void bls381_ctx_destroy(bls381_ctx* c) {
     (void)hipSetDevice(c->device);
     for (auto& kv : c->progs) (void)hipFree(kv.second.d_blocks);
     for (DevBuf* b : {&c->user_in, &c->user_in2, &c->user_in3, &c->user_in4, &c->user_out, &c->flags, &c->bufA, &c->bufB,
-                      &c->bufC, &c->bufD, &c->bufE, &c->bufTmp, &c->zflags, &c->ilist})
+                      &c->bufC, &c->bufD, &c->bufE, &c->bufF, &c->bufTmp, &c->zflags, &c->ilist})
         b->release();
     for (auto& b : c->vbuf) b.release();
     c->wit.release();
@@ -351,6 +357,7 @@ extern "C" void bls381_ctx_destroy(bls381_ctx* c) {
     if (c->d_trash) (void)hipFree(c->d_trash);
     if (c->h_bad) (void)hipHostFree(c->h_bad);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_chain) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->pipe_ev) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -448,6 +455,38 @@ static int unpack(bls381_ctx* c, const void* soa, void* aos_dev, int n, int npad
 
 enum { CHUNK = 1 << 16 };
 
+// Part 2 of the final exponentiation through the squaring-chain kernel: six programs and five chain runs over one
+// slot array (see build_final_exp_chain_part).  Batches of at most SMALL_BATCH items keep the single program: one
+// wave per SIMD is all a small batch gives either form, and the single program's 16-lane variant is the shorter one.
+// BLS381_FE2_CHAIN=0 keeps the single program for every size, =1 takes this path for every size.
+static bool use_chain(const bls381_ctx* c, int n) {
+    static const int forced = getenv("BLS381_FE2_CHAIN") ? atoi(getenv("BLS381_FE2_CHAIN")) : -1;
+    if (forced == 0) return false;
+    if (forced == 1) return true;
+    return c->auto_geometry && n > SMALL_BATCH;
+}
+static int final_exp_chain(bls381_ctx* c, void* fout, int n, int npad) {
+    HIPCHK(c->bufF.ensure(soa_bytes(FE2_CHAIN_SLOTS, npad)));
+    char* const F = (char*)c->bufF.p;
+    auto area = [&](int slot) { return (void*)(F + (size_t)slot * 48 * npad); };
+    // (the area each chain run squares, and where each program's results go)
+    const int chain_in[5] = {FE2_AREA_A, FE2_AREA_C, FE2_AREA_D, FE2_AREA_E, FE2_AREA_C};
+    const int prog_out[5] = {FE2_AREA_A, FE2_AREA_C, FE2_AREA_D, FE2_AREA_E, FE2_AREA_C};
+    int ev = 0, rc;
+    HIPCHK(hipEventRecord(c->ev_chain[ev++], c->stream));
+    for (int k = 0; k < 5; k++) {
+        const std::string prog = "fe2s" + std::to_string(k);
+        if ((rc = run_program(c, prog.c_str(), k == 0 ? c->bufC.p : (void*)F, area(prog_out[k]), n, npad))) return rc;
+        HIPCHK(hipEventRecord(c->ev_chain[ev++], c->stream));
+        HIPCHK(launch_cyc_chain(c->stream, area(chain_in[k]), F, n, npad));
+        HIPCHK(hipEventRecord(c->ev_chain[ev++], c->stream));
+    }
+    if ((rc = run_program(c, "fe2s5", F, fout, n, npad))) return rc;
+    HIPCHK(hipEventRecord(c->ev_chain[ev++], c->stream));
+    c->chain_timed = true;
+    return 0;
+}
+
 // final exponentiation of `n` Fq12 sitting in slots 0..11 of `fin` (SoA); result to slots 0..11 of `fout`.
 // Records ev[3] between the inversion and the second program.
 static int final_exp_soa(bls381_ctx* c, const void* fin, void* fout, int n, int npad, uint8_t* zero_dev,
@@ -459,6 +498,8 @@ static int final_exp_soa(bls381_ctx* c, const void* fin, void* fout, int n, int 
                        c->d_consts, zero_dev);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[3], c->stream));
+    c->chain_timed = false;
+    if (std::string(part2) == "fe2" && use_chain(c, n)) return final_exp_chain(c, fout, n, npad);
     return run_program(c, part2, c->bufC.p, fout, n, npad);
 }
 
@@ -1595,6 +1636,48 @@ extern "C" int bls381_debug_constants(uint32_t* out, size_t capacity_fp) {
     std::memcpy(out, c.data(), c.size() * 4);
     return 0;
 }
+// How the last final exponentiation's second part split its time, when it went through the squaring-chain kernel:
+// ms[0] = the five chain launches together, ms[1] = the six programs around them together; *used = 0 when it ran as
+// the single program instead (ms untouched).
+extern "C" int bls381_last_chain_timing(bls381_ctx* c, float ms[2], int* used) {
+    CTX_GUARD(c);
+    if (!ms || !used) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    *used = c->chain_timed ? 1 : 0;
+    if (!c->chain_timed) return 0;
+    float chain = 0, total = 0, t = 0;
+    for (int k = 0; k < 5; k++) {
+        HIPCHK(hipEventElapsedTime(&t, c->ev_chain[2 * k + 1], c->ev_chain[2 * k + 2]));
+        chain += t;
+    }
+    HIPCHK(hipEventElapsedTime(&total, c->ev_chain[0], c->ev_chain[11]));
+    ms[0] = chain; ms[1] = total - chain;
+    return 0;
+}
+
+// The squaring-chain kernel on its own: n cyclotomic Fq12 values as 12 x 12 u32 canonical words with Montgomery factor
+// 2^392 (the form the interpreter's raw loads and stores use) -> the six kept powers, 72 x 12 u32 each.
+extern "C" int bls381_debug_cyc_chain(bls381_ctx* c, const uint32_t* in, size_t n, uint32_t* out) {
+    CTX_GUARD(c);
+    if (n == 0) return 0;
+    if (!in || !out) return fail(BLS381_ERR_INVALID, "NULL buffer");
+    if (n > CHUNK) return fail(BLS381_ERR_INVALID, "at most 65,536 values per call");
+    const int m = (int)n, npad = pad_elems(n);
+    int rc;
+    if ((rc = h2d(c, c->user_in, in, n * 576))) return rc;
+    HIPCHK(c->user_out.ensure(n * 576 * CHAIN_KEPT));
+    HIPCHK(c->bufA.ensure(soa_bytes(12, npad)));
+    HIPCHK(c->bufB.ensure(soa_bytes(12 * CHAIN_KEPT, npad)));
+    if ((rc = pack(c, c->user_in.p, c->bufA.p, m, npad, 12, 0))) return rc;
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    HIPCHK(launch_cyc_chain(c->stream, c->bufA.p, c->bufB.p, m, npad));
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    if ((rc = unpack(c, c->bufB.p, c->user_out.p, m, npad, 12 * CHAIN_KEPT, 0))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipEventElapsedTime(&c->last_ms[2], c->ev[0], c->ev[1]);
+    HIPCHK(hipMemcpy(out, c->user_out.p, n * 576 * CHAIN_KEPT, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int bls381_last_timing(bls381_ctx* c, float ms[4]) {
     if (!c || !ms) return fail(BLS381_ERR_INVALID, "NULL argument");
     std::lock_guard<std::mutex> lock_(c->mu);

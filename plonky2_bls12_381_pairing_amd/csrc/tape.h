@@ -107,6 +107,10 @@ Dag build_ell();
 enum { FE_CARRY = 21 };
 Dag build_final_exp_part1();
 Dag build_final_exp_part2(bool cyclotomic_hard_part);
+// Part 2 as six programs with the squaring-chain kernel between them (see tower_sym.cpp): slot areas of the array
+// they share, and the slots that array has.
+enum { FE2_AREA_A = 72, FE2_AREA_B = 84, FE2_AREA_C = 96, FE2_AREA_D = 108, FE2_AREA_E = 120, FE2_AREA_G = 132, FE2_CHAIN_SLOTS = 144 };
+Dag build_final_exp_chain_part(int part);  // part 0..5
 // easy_part_native alone (part 2 of it; part 1 is build_final_exp_part1).
 Dag build_easy_part2();
 // hard_part_native on an arbitrary Fq12 (generic squarings).  gin 12 -> gout 12.

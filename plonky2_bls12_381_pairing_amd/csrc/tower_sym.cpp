@@ -153,6 +153,9 @@ static int materialise_for_store(Dag& d, Tower& T, SFp a) {
 void Tower::out(SFp a, int slot) {
     d_.store_out(d_.fmul(materialise_for_store(d_, *this, a), d_.load_const(C_OUT)), slot);
 }
+void Tower::out_raw(SFp a, int slot) {
+    d_.store_out(d_.fmul(materialise_for_store(d_, *this, a), d_.load_const(C_ONE)), slot);
+}
 void Tower::out_canon(SFp a, int slot) {
     d_.store_out(d_.fmul(materialise_for_store(d_, *this, a), d_.load_const(C_OUT_CANON)), slot);
 }
@@ -480,6 +483,17 @@ void Tower::out12(const SFq12& a, int base) {
     for (int i = 0; i < 12; i++) out(v[i], base + i);
 }
 
+SFq12 Tower::in12_raw(int base) {
+    SFp v[12];
+    for (int i = 0; i < 12; i++) v[i] = in_raw(base + i);
+    return {{{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}}, {{v[6], v[7]}, {v[8], v[9]}, {v[10], v[11]}}};
+}
+void Tower::out12_raw(const SFq12& a, int base) {
+    const SFp v[12] = {a.c0.c0.c0, a.c0.c0.c1, a.c0.c1.c0, a.c0.c1.c1, a.c0.c2.c0, a.c0.c2.c1,
+                       a.c1.c0.c0, a.c1.c0.c1, a.c1.c1.c0, a.c1.c1.c1, a.c1.c2.c0, a.c1.c2.c1};
+    for (int i = 0; i < 12; i++) out_raw(v[i], base + i);
+}
+
 // ------------------------------------------------------------------ builders
 // The Miller loop walks the bits of |x| below the top one, MSB first
 // (BitIteratorBE::without_leading_zeros([BLS_X]).skip(1)): 63 doublings, 5 additions.
@@ -667,6 +681,67 @@ Dag build_final_exp_part2(bool cyclotomic_hard_part) {
     SFq12 f = easy_part_tail(T);
     f = T.hard_part(f, cyclotomic_hard_part);
     T.out12(f, 0);
+    d.optimise();
+    return d;
+}
+
+// The final exponentiation's second part in six programs around five runs of the squaring-chain kernel
+// (cyc_chain.h).  hard_part_native (/root/reference/src/native/final_exponentiation.rs:44-72) raises to |x| five times;
+// each of those is one chain run (63 squarings that keep a^(2^k) for the six set bits k of |x|) followed by the
+// product of the six kept values, which the next program forms: the same 63 squarings and 5 multiplications as
+// pow_native (/root/reference/src/native/fin_exp_helpers.rs:60-82), in another order, and the same field element.
+// All programs but the first read one slot array F and write into it (canonical words, factor 2^392):
+//   F[0..72) the six kept values of the latest chain run, F[72..) twelve-slot areas A, B, C, D, E, G (FE2_AREA_*).
+static SFq12 chain_product(Tower& T) {
+    SFq12 s[6];
+    for (int k = 0; k < 6; k++) s[k] = T.in12_raw(12 * k);
+    return T.mul(T.mul(T.mul(s[0], s[1]), T.mul(s[2], s[3])), T.mul(s[4], s[5]));
+}
+Dag build_final_exp_chain_part(int part) {
+    Dag d;
+    Tower T(d);
+    switch (part) {
+        case 0: {  // carry of part 1 -> r = easy part (A), y0 = r^2 (B); the first chain runs on A
+            d.n_in = FE_CARRY; d.n_out = 24;
+            SFq12 r = easy_part_tail(T);
+            T.out12_raw(r, 0);
+            T.out12_raw(T.cyclotomic_sqr(r), 12);
+            break;
+        }
+        case 1: {  // y1 = conj(r^|x|) conj(r) -> C; the second chain runs on C        (:46-48)
+            d.n_in = FE2_AREA_A + 12; d.n_out = 12;
+            SFq12 r = T.in12_raw(FE2_AREA_A);
+            T.out12_raw(T.mul(T.conj(chain_product(T)), T.conj(r)), 0);
+            break;
+        }
+        case 2: {  // y1 = conj(y1) conj(y1^|x|) -> D; the third chain runs on D       (:49-52)
+            d.n_in = FE2_AREA_C + 12; d.n_out = 12;
+            SFq12 y1 = T.in12_raw(FE2_AREA_C);
+            T.out12_raw(T.mul(T.conj(y1), T.conj(chain_product(T))), 0);
+            break;
+        }
+        case 3: {  // y1 = frobenius(y1) conj(y1^|x|) -> E, r = r y0 -> G; the fourth chain runs on E   (:53-57)
+            d.n_in = FE2_AREA_D + 12; d.n_out = 24;
+            SFq12 r = T.in12_raw(FE2_AREA_A), y0 = T.in12_raw(FE2_AREA_B), y1 = T.in12_raw(FE2_AREA_D);
+            T.out12_raw(T.mul(T.frobenius(y1, 1), T.conj(chain_product(T))), 0);
+            T.out12_raw(T.mul(r, y0), 12);
+            break;
+        }
+        case 4: {  // y0 = conj(y1^|x|) -> C; the fifth chain runs on C                 (:58-59)
+            d.n_in = 72; d.n_out = 12;
+            T.out12_raw(T.conj(chain_product(T)), 0);
+            break;
+        }
+        default: {  // y2 = conj(y0^|x|); result = r (conj(y1) y2 frobenius^2(y1))      (:60-71), boundary form
+            d.n_in = FE2_AREA_G + 12; d.n_out = 12;
+            SFq12 y1 = T.in12_raw(FE2_AREA_E), r = T.in12_raw(FE2_AREA_G);
+            SFq12 y2 = T.conj(chain_product(T));
+            SFq12 y0 = T.frobenius(y1, 2);
+            SFq12 m = T.mul(T.mul(T.conj(y1), y2), y0);
+            T.out12(T.mul(r, m), 0);
+            break;
+        }
+    }
     d.optimise();
     return d;
 }

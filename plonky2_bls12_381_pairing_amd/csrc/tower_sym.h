@@ -55,6 +55,10 @@ class Tower {
     SFp in_canon(int slot) { return SFp{d_.fmul(d_.load_in(slot), d_.load_const(C_IN_CANON))}; }
     void out_canon(SFp a, int slot);
     void out(SFp a, int slot);
+    // Values handed from one program to the next keep the factor 2^392: canonical words in, no multiplication; on the
+    // way out one multiplication by one brings a sum back into the range a store accepts.
+    SFp in_raw(int slot) { return SFp{d_.load_in(slot)}; }
+    void out_raw(SFp a, int slot);
 
     // ---- Fq2
     SFq2 zero2() { return {SZERO, SZERO}; }
@@ -129,6 +133,8 @@ class Tower {
     // load / store helpers (ark flat order)
     SFq12 in12(int base);
     void out12(const SFq12& a, int base);
+    SFq12 in12_raw(int base);
+    void out12_raw(const SFq12& a, int base);
 
    private:
     Dag& d_;

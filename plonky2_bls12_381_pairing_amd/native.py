@@ -488,6 +488,14 @@ class Context:
         check(lib.bls381_last_timing(self._h, ms))
         return list(ms)
 
+    def last_chain_timing(self):
+        """(ms of the five squaring-chain launches, ms of the six programs around them) of the last final
+        exponentiation, or None when it ran as the single program."""
+        ms = (C.c_float * 2)()
+        used = C.c_int(0)
+        check(lib.bls381_last_chain_timing(self._h, ms, C.byref(used)))
+        return (ms[0], ms[1]) if used.value else None
+
     def calibrate_mac_rate(self):
         v = C.c_double(0)
         check(lib.bls381_calibrate_mac_rate(self._h, C.byref(v)))

@@ -1210,3 +1210,42 @@ def test_field_elements_not_below_p_are_refused(ctx):
     x[1, 66:72] = pm1
     assert ctx.conjugate_batch(x).shape == (2, 72)
     assert np.array_equal(ctx.pairing_batch(g1, g2), good)
+
+
+def _raw392(vals):
+    """Fq12 values -> (n, 144) u32: canonical words carrying the kernels' internal Montgomery factor 2^392."""
+    out = np.zeros((len(vals), 144), dtype=np.uint32)
+    for i, v in enumerate(vals):
+        out[i] = [w for c in R.fq12_flatten_ark(v) for w in R.fq_to_u32_limbs(c * (1 << 392) % R.P)]
+    return out
+
+
+def test_squaring_chain_kernel(ctx):
+    """The kernel that runs the hard part's 63-squaring chains in registers (three waves per 64 elements, generated
+    assembly): the six powers a^(2^k), k = 16, 48, 57, 60, 62, 63, it keeps against the oracle's plain squarings, for
+    batch sizes on both sides of a workgroup's 64 elements; their product is pow_native(a, BLS_X)."""
+    import ctypes as C
+    from plonky2_bls12_381_pairing_amd import _lib
+    xs = [R.myfq12_to_fq12(R.easy_part_native(R.myfq12_from_fq12(x))) for x in H.random_fq12(3, 6301)]   # cyclotomic subgroup
+    want = []
+    for x in xs:
+        row, cur = [], x
+        for k in range(1, 64):
+            cur = R.fq12_square(cur)
+            if (R.BLS_X >> k) & 1:
+                row.append(cur)
+        assert len(row) == 6
+        prod = row[0]
+        for v in row[1:]:
+            prod = R.fq12_mul(prod, v)
+        assert prod == R.fq12_pow(x, R.BLS_X)
+        want.append(_raw392(row).reshape(-1))
+    want = np.array(want)
+    inv392 = R.fq_inv((1 << 392) % R.P)
+    for n in (1, 3, 64, 65, 200):
+        a = np.ascontiguousarray(_raw392([xs[i % 3] for i in range(n)]))
+        out = np.zeros((n, 6 * 144), dtype=np.uint32)
+        _lib.check(_lib.lib.bls381_debug_cyc_chain(ctx.handle, a.ctypes.data_as(_lib.u32p), n, out.ctypes.data_as(_lib.u32p)))
+        for i in range(n):
+            assert np.array_equal(out[i], want[i % 3]), (n, i)
+    assert inv392  # (the raw form decodes with this factor; kept here for readers of a failing comparison)

@@ -340,3 +340,47 @@ def test_rust_ffi_declarations_match_the_header():
     for name in ("bls381_pairing_batch", "bls381_multi_miller_loop", "bls381_final_exp_batch", "bls381_pairing_witness_batch",
                  "bls381_pairing_witness_aux_batch", "bls381_fq12_inverse_limbs_batch", "bls381_g2_prepare_batch", "bls381_ell_batch"):
         assert name in rust, name
+
+
+def test_chained_final_exponentiation_programs():
+    """Part 2 of the final exponentiation as the library runs it on large batches: six step programs with the
+    squaring-chain kernel between them.  The programs run in the big-integer interpreter, the oracle's squarings stand
+    in for the kernel (the GPU test test_squaring_chain_kernel checks the kernel against the same squarings): the
+    result is the reference's pairing value, and equal to the single program's."""
+    R392 = pow(2, 392, R.P)
+    INV392 = R.fq_inv(R392)
+
+    def chain(area):                                      # 12 raw values -> the six kept powers, 72 raw values
+        x = R.fq12_from_flat_ark([v * INV392 % R.P for v in area])
+        kept = []
+        for k in range(1, 64):
+            x = R.fq12_square(x)
+            if (R.BLS_X >> k) & 1:
+                kept += [c * R392 % R.P for c in R.fq12_flatten_ark(x)]
+        assert len(kept) == 72
+        return kept
+
+    ps, qs = H.random_pairs(1, 977)
+    p, q = ps[0], qs[0]
+    ml = R.multi_miller_loop([p], [q])
+    mid = S.run_program(S.get_program("fe1"), [M(x) for x in R.fq12_flatten_ark(ml)])
+    mid[0] = M(R.fq_inv(F(mid[0])))
+    A, Bq, Cc, Dd, E, G = 72, 84, 96, 108, 120, 132
+    Fa = [0] * 144
+    progs = [S.get_program("fe2s%d" % k) for k in range(6)]
+    assert [pr["n_in"] for pr in progs] == [21, 84, 108, 120, 72, 144] and [pr["n_out"] for pr in progs] == [24, 12, 12, 24, 12, 12]
+    out = S.run_program(progs[0], mid)
+    Fa[A:A + 24] = out
+    # the easy part's value sits in A, in the programs' internal form
+    easy = R.myfq12_to_fq12(R.easy_part_native(R.myfq12_from_fq12(ml)))
+    assert [v * INV392 % R.P for v in Fa[A:A + 12]] == R.fq12_flatten_ark(easy)
+    for k, (src, dst, n_out) in enumerate([(A, Cc, 12), (Cc, Dd, 12), (Dd, E, 24), (E, Cc, 12)], start=1):
+        Fa[0:72] = chain(Fa[src:src + 12])
+        out = S.run_program(progs[k], Fa[:progs[k]["n_in"]])
+        Fa[dst:dst + n_out] = out
+    Fa[0:72] = chain(Fa[Cc:Cc + 12])
+    out = S.run_program(progs[5], Fa)
+    got = R.fq12_from_flat_ark([F(x) for x in out])
+    assert got == R.native_pairing([p], [q])
+    single = S.run_program(S.get_program("fe2"), mid)
+    assert out == single
