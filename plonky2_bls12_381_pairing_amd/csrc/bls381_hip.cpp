@@ -396,7 +396,7 @@ static hipError_t launch_vm_k(bls381_ctx* c, const DevProgram& p, const uint4* g
     if (c->d_prof) return launch_vm_kt<K, TAG_PROFILE>(c, p, gin, gout, gtmp, n, npad);
     const std::string base = base_name(p.host.name);
     if (base == "miller" || base == "millers" || base == "millerfq") return launch_vm_kt<K, TAG_MILLER>(c, p, gin, gout, gtmp, n, npad);
-    if (base == "fe2") return launch_vm_kt<K, TAG_FINAL_EXP>(c, p, gin, gout, gtmp, n, npad);
+    if (base == "fe2" || base.rfind("fe2s", 0) == 0) return launch_vm_kt<K, TAG_FINAL_EXP>(c, p, gin, gout, gtmp, n, npad);
     return launch_vm_kt<K, TAG_AUX>(c, p, gin, gout, gtmp, n, npad);
 }
 
@@ -669,6 +669,10 @@ extern "C" int bls381_ctx_reserve(bls381_ctx* c, size_t max_items) {
     size_t tmp = 0;
     std::vector<std::string> names = {"miller", "millers", "fe1", "fe2"};
     if (c->auto_geometry) for (const char* nm : {"miller@16", "millers@16", "fe1@16", "fe2@16"}) names.push_back(nm);
+    if (use_chain(c, (int)std::min<size_t>(max_items, CHUNK))) {  // large batches: the chained form of part 2 and its slot array
+        HIPCHK(c->bufF.ensure(soa_bytes(FE2_CHAIN_SLOTS, npad)));
+        for (int k = 0; k < 6; k++) names.push_back("fe2s" + std::to_string(k));
+    }
     for (const std::string& nm : names) {
         if (!c->progs.count(nm)) { int rc = upload_program(c, nm); if (rc) return rc; }
         tmp = std::max(tmp, spill_bytes(c->progs[nm], npad));

@@ -147,26 +147,29 @@ class Prog:
         return written
 
 
-def dot2(p, a, b, c, d, r, m, acc):
+def dot2(p, a, b, c, d, r, m, acc, sp=SP, sn=SN):
     """r = (a b + c d) / 2^392 + (multiple of p) / 2^392, as fp28_mulacc<true> (fp28_dev.h): one accumulator, shifted
-    down 28 bits per column."""
+    down 28 bits per column.  c = d = None: the single product a b.  sp, sn: the scalar registers that hold the digits
+    of p and -1/p mod 2^28."""
     first = True
     for k in range(D):
         for i in range(k + 1):
             p.mad_i64(acc, a[i], b[k - i], "zero" if first else None)
             first = False
-            p.mad_i64(acc, c[i], d[k - i])
+            if c is not None:
+                p.mad_i64(acc, c[i], d[k - i])
         for j in range(k):
-            p.mad_u64(acc, m[j], ("s", SP + k - j))
-        p.emit("mul_lo", m[k], acc, ("s", SN))
+            p.mad_u64(acc, m[j], ("s", sp + k - j))
+        p.emit("mul_lo", m[k], acc, ("s", sn))
         p.emit("and_mask", m[k], m[k])
-        p.mad_u64(acc, m[k], ("s", SP))
+        p.mad_u64(acc, m[k], ("s", sp))
         p.emit("ashr64", acc)
     for k in range(D, 2 * D - 1):
         for i in range(k - D + 1, D):
             p.mad_i64(acc, a[i], b[k - i])
-            p.mad_i64(acc, c[i], d[k - i])
-            p.mad_u64(acc, m[i], ("s", SP + k - i))
+            if c is not None:
+                p.mad_i64(acc, c[i], d[k - i])
+            p.mad_u64(acc, m[i], ("s", sp + k - i))
         p.emit("and_mask", r[k - D], acc)
         p.emit("ashr64", acc)
     p.emit("mov", r[D - 1], acc)
