@@ -266,6 +266,15 @@ int bls381_last_chain_timing(bls381_ctx*, float ms[2], int* used);
  * out = {operand reads of trace rows, reads the plan serves from LDS, plan violations (must be 0), operations}.
  * Host-only: needs no GPU. */
 int bls381_debug_witness_cache_plan(int lanes_per_proof, int cache_rows, uint64_t out[4]);
+/* The operations the witness kernel runs in one phase (0: before the Fq12 inversion, 1: after), in its order:
+ * ops[3 i .. 3 i + 2] = {dst, a, b} of operation i (dst: row | kind << 28; a, b: space << 30 | index; spaces 0 row,
+ * 1 constant, 2 circuit input), levels = offsets of the dependency levels into them.  Rows from the trace's row count
+ * on are the kernel's own (products' left operands times 2^392); constants 24..47 are constants 0..23 times 2^392,
+ * constant 48 is 2^784; inputs 6..11 are inputs 0..5 times 2^392; a product is a * b / 2^392.
+ * sizes = {operations, levels + 1, trace rows, kernel's own rows}; with null buffers only sizes is filled.
+ * No counterpart in the reference: test access to the program the trace is computed by. */
+int bls381_debug_witness_ops(int phase, uint32_t* ops, size_t ops_capacity, uint32_t* levels, size_t levels_capacity,
+                             uint64_t sizes[4]);
 /* The interpreter's constant table: C_COUNT rows of 16 u32 (14 digits of 28 bits, zero padded). */
 int bls381_debug_constants(uint32_t* out, size_t capacity_fp);
 /* ---- the other witness generators of the reference --------------------------------------------

@@ -135,6 +135,7 @@ _sig("bls381_multi_ctx_verify_batch", C.c_int, ctxp, u8p, u8p, u8p, C.c_size_t, 
 _sig("bls381_debug_program", C.c_int, C.c_char_p, C.c_int, C.c_int, u32p, u32p, C.c_size_t, u32p)
 _sig("bls381_debug_constants", C.c_int, u32p, C.c_size_t)
 _sig("bls381_debug_witness_cache_plan", C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64))
+_sig("bls381_debug_witness_ops", C.c_int, C.c_int, u32p, C.c_size_t, u32p, C.c_size_t, C.POINTER(C.c_uint64))
 _sig("bls381_debug_profile", C.c_int, C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64))
 _sig("bls381_debug_fp_mul", C.c_int, ctxp, u32p, u32p, C.c_size_t, u32p, u32p)
 _sig("bls381_debug_fp_inverse", C.c_int, ctxp, u32p, C.c_size_t, u32p, C.POINTER(C.c_uint8))
@@ -153,7 +154,7 @@ EXPORTED = [
     "bls381_pairing_witness_batch", "bls381_pairing_witness_mul_rows", "bls381_pairing_witness_aux_batch", "bls381_pairing_witness_batch_dev", "bls381_pairing_batch_dev", "bls381_pairing_batch_dev_noalloc", "bls381_miller_loop_batch_dev",
     "bls381_final_exp_batch_dev", "bls381_g2_prepared_create", "bls381_g2_prepared_destroy",
     "bls381_fq_sqrt_limbs_batch", "bls381_fq2_sqrt_limbs_batch", "bls381_fq2_inverse_limbs_batch", "bls381_fq6_inverse_limbs_batch",
-    "bls381_miller_loop_fixed_q_batch", "bls381_pairing_fixed_q_batch", "bls381_pairing_fixed_q_batch_dev", "bls381_debug_program", "bls381_debug_constants", "bls381_debug_witness_cache_plan", "bls381_debug_profile", "bls381_debug_fp_mul", "bls381_debug_fp_inverse", "bls381_debug_cyc_chain", "bls381_last_chain_timing", "bls381_last_timing",
+    "bls381_miller_loop_fixed_q_batch", "bls381_pairing_fixed_q_batch", "bls381_pairing_fixed_q_batch_dev", "bls381_debug_program", "bls381_debug_constants", "bls381_debug_witness_cache_plan", "bls381_debug_witness_ops", "bls381_debug_profile", "bls381_debug_fp_mul", "bls381_debug_fp_inverse", "bls381_debug_cyc_chain", "bls381_last_chain_timing", "bls381_last_timing",
     "bls381_calibrate_mac_rate", "bls381_g1_decompress_batch", "bls381_g2_decompress_batch", "bls381_g1_compress_batch",
     "bls381_g2_compress_batch", "bls381_g1_aggregate_batch", "bls381_g2_aggregate_batch",
     "bls381_multi_ctx_create", "bls381_multi_ctx_destroy", "bls381_multi_ctx_devices", "bls381_multi_ctx_pairing_batch",

@@ -1582,25 +1582,46 @@ extern "C" int bls381_debug_witness_cache_plan(int lanes_per_proof, int cache_ro
         out[0] += reads; out[1] += hits; out[3] += ops.size();
         std::vector<int64_t> entry(WCACHE_MAX_ROWS, -1);
         const auto& ls = P.level_start[ph];
-        // the level assignment: every row of the phase is made once, from rows of earlier levels (or of outside the phase)
+        // the level assignment: every row of the phase (the circuit's and the shadow rows made for its products) is
+        // made once, from rows of earlier levels (or of outside the phase)
         const size_t row_lo = ph == 0 ? 0 : P.gen_start + 12, row_hi = ph == 0 ? P.gen_start : P.n_rows;
-        const size_t NOT_MADE = ~(size_t)0;
-        std::vector<size_t> made_in(row_hi - row_lo, NOT_MADE);
+        const size_t sh_lo = P.n_rows + (ph == 0 ? 0 : P.n_shadow[0]), sh_hi = sh_lo + P.n_shadow[ph];
+        const size_t NOT_MADE = ~(size_t)0, OUTSIDE = ~(size_t)0 - 1;
+        auto slot_of_row = [&](size_t row) -> size_t {  // position among the phase's rows
+            if (row >= row_lo && row < row_hi) return row - row_lo;
+            if (row >= sh_lo && row < sh_hi) return (row_hi - row_lo) + (row - sh_lo);
+            return OUTSIDE;
+        };
+        std::vector<size_t> made_in((row_hi - row_lo) + (sh_hi - sh_lo), NOT_MADE);
+        // rounds without barriers: the iteration that made a row, and the last iteration so far in which the wave waits
+        // for its memory operations (it loads from global memory, or an operation asks for the wait)
+        std::vector<int64_t> made_iter(made_in.size(), -1);
+        int64_t iteration = -1, last_wait = -1;
         for (size_t l = 0; l + 1 < ls.size(); l++)
             for (uint32_t i = ls[l]; i < ls[l + 1]; i += (uint32_t)lanes_per_proof) {
                 const uint32_t e = std::min(i + (uint32_t)lanes_per_proof, ls[l + 1]);
+                iteration++;
+                bool waits = false;
                 for (uint32_t j = i; j < e; j++) {
                     const uint32_t kind = ops[j].dst >> 28;
                     const uint32_t refs[2] = {ops[j].a, ops[j].b};
                     const size_t row = ops[j].dst & WROW_MASK;
-                    if (row < row_lo || row >= row_hi || made_in[row - row_lo] != NOT_MADE) out[2]++;
-                    else made_in[row - row_lo] = l;
+                    if (slot_of_row(row) == OUTSIDE || made_in[slot_of_row(row)] != NOT_MADE) out[2]++;
+                    else { made_in[slot_of_row(row)] = l; made_iter[slot_of_row(row)] = iteration; }
+                    if (ops[j].dst & WDRAIN_FLAG) waits = true;
                     for (int k = 0; k < (kind == WK_NEG || kind == WK_INV ? 1 : 2); k++) {
                         const size_t src = refs[k] & WROW_MASK;
-                        if ((refs[k] >> 30) == 0 && src >= row_lo && src < row_hi && (made_in[src - row_lo] == NOT_MADE || made_in[src - row_lo] >= l))
+                        if ((refs[k] >> 30) == 0 && slot_of_row(src) != OUTSIDE && (made_in[slot_of_row(src)] == NOT_MADE || made_in[slot_of_row(src)] >= l))
                             out[2]++;
-                        if ((refs[k] >> 30) != 0) { if (refs[k] & WCACHE_FLAG) out[2]++; continue; }
-                        if (!(refs[k] & WCACHE_FLAG)) continue;
+                        // a row of the other phase must exist by now: phase 0 reads nothing of phase 1, shadow rows included
+                        if ((refs[k] >> 30) == 0 && slot_of_row(src) == OUTSIDE && ph == 0 && src >= P.gen_start) out[2]++;
+                        if ((refs[k] >> 30) != 0) { if (refs[k] & WCACHE_FLAG) out[2]++; waits = true; continue; }
+                        if (!(refs[k] & WCACHE_FLAG)) {
+                            // a row from global memory: stored before an earlier wait of the wave, or this operation waits
+                            waits = true;
+                            if (P.rounds && slot_of_row(src) != OUTSIDE && !(made_iter[slot_of_row(src)] < last_wait) && !(ops[j].dst & WDRAIN_FLAG)) out[2]++;
+                            continue;
+                        }
                         const uint32_t sl = (refs[k] >> WCACHE_SLOT_SHIFT) & WCACHE_SLOT_MASK;
                         if ((int)sl >= cache_rows || entry[sl] != (int64_t)(refs[k] & WROW_MASK)) out[2]++;
                     }
@@ -1613,13 +1634,14 @@ extern "C" int bls381_debug_witness_cache_plan(int lanes_per_proof, int cache_ro
                     written.push_back(sl);
                     entry[sl] = ops[j].dst & WROW_MASK;
                 }
+                if (waits) last_wait = iteration;
             }
         for (size_t m : made_in) if (m == NOT_MADE) out[2]++;
         // apart from the cache fields, a level holds the operations the program holds for it (in any order)
         const uint32_t plan_bits = WCACHE_FLAG | (WCACHE_SLOT_MASK << WCACHE_SLOT_SHIFT);
         auto plain = [&](const WitnessOp& o) {
             const bool ta = (o.a >> 30) == 0, tb = (o.b >> 30) == 0;
-            return std::array<uint32_t, 3>{o.dst & ~plan_bits, ta ? o.a & ~plan_bits : o.a, tb ? o.b & ~plan_bits : o.b};
+            return std::array<uint32_t, 3>{o.dst & ~(plan_bits | WDRAIN_FLAG), ta ? o.a & ~plan_bits : o.a, tb ? o.b & ~plan_bits : o.b};
         };
         if (ops.size() != P.ops[ph].size()) out[2]++;
         else
@@ -1631,6 +1653,22 @@ extern "C" int bls381_debug_witness_cache_plan(int lanes_per_proof, int cache_ro
                 if (x != y) out[2]++;
             }
     }
+    return 0;
+}
+// The operations the witness kernel runs in one phase, in its order, with their level boundaries: ops as
+// {dst, a, b} words (WitnessOp), levels as offsets into them.  sizes[0..3] = operations, levels + 1, rows of the
+// trace, shadow rows of both phases; with null buffers only the sizes are returned.
+extern "C" int bls381_debug_witness_ops(int phase, uint32_t* ops, size_t ops_capacity, uint32_t* levels, size_t levels_capacity,
+                                        uint64_t sizes[4]) {
+    if (phase < 0 || phase > 1 || !sizes) return fail(BLS381_ERR_INVALID, "bad argument");
+    const WitnessProgram& P = witness_program();
+    if (!P.error.empty()) return fail(BLS381_ERR_INVALID, P.error);
+    sizes[0] = P.ops[phase].size(); sizes[1] = P.level_start[phase].size(); sizes[2] = P.n_rows; sizes[3] = P.n_shadow[0] + P.n_shadow[1];
+    if (!ops && !levels) return 0;
+    if (!ops || !levels || ops_capacity < sizes[0] || levels_capacity < sizes[1]) return fail(BLS381_ERR_INVALID, "capacity too small");
+    static_assert(sizeof(WitnessOp) == 12, "WitnessOp is three words");
+    std::memcpy(ops, P.ops[phase].data(), P.ops[phase].size() * sizeof(WitnessOp));
+    std::memcpy(levels, P.level_start[phase].data(), P.level_start[phase].size() * 4);
     return 0;
 }
 extern "C" int bls381_debug_constants(uint32_t* out, size_t capacity_fp) {

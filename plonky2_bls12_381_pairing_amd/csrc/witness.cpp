@@ -7,10 +7,12 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <queue>
 
 #include "bls381_constants.h"
 #include "fp_dev.h"
 #include "fp_asm_gen.h"
+#include "fp28_dev.h"
 
 namespace bls381 {
 
@@ -319,9 +321,11 @@ WitnessProgram build_program(int group) {
     (void)mul(w, r2, y1);
 
     P.group = group;
+    {   // BLS381_WIT_SCHED=levels: dependency levels with a barrier after each; default: rounds in row order
+        const char* e = getenv("BLS381_WIT_SCHED");
+        P.rounds = !(e && std::string(e) == "levels") && group > 1;
+    }
     P.n_rows = w.kinds.size();
-    // row references share their word with the row-cache fields: 18 bits of row number
-    if (P.n_rows > (size_t)WROW_MASK + 1) { P.error = "witness trace has more rows than an operand reference can name"; return P; }
     P.kinds = w.kinds;
     for (uint8_t kd : w.kinds) P.counts[kd]++;
     P.mul_index.assign(P.n_rows, 0xffffffffu);
@@ -329,59 +333,147 @@ WitnessProgram build_program(int group) {
         uint32_t k = 0;
         for (size_t r = 0; r < P.n_rows; r++) if (P.kinds[r] == WK_MUL) P.mul_index[r] = k++;
     }
+    const size_t phase_lo[2] = {0, P.gen_start + 12}, phase_hi[2] = {P.gen_start, P.n_rows};
+    for (int phase = 0; phase < 2; phase++)
+        for (size_t i = phase_lo[phase]; i < phase_hi[phase]; i++)
+            P.circuit_ops[phase].push_back(WitnessOp{(uint32_t)i | ((uint32_t)w.kinds[i] << 28), w.ra[i], w.rb[i]});
+
+    // ---- what the kernel runs (WitnessProgram::ops): products get a left operand times 2^392
+    struct XRow { uint8_t kind; uint32_t id, a, b; };
+    std::vector<XRow> xrows[2];
+    {
+        auto is_row = [](uint32_t ref) { return (ref >> 30) == 0; };
+        auto times_r = [](uint32_t ref) {  // a constant or an input in its form times 2^392
+            return (ref >> 30) == 1 ? cst((int)(ref & WREF_MASK) + WC_TIMES_R) : inp((int)(ref & WREF_MASK) + WIN_COUNT);
+        };
+        // in how many products between two rows a row is a factor: the factor used more often gets the shadow
+        std::vector<uint32_t> uses(P.n_rows, 0);
+        for (size_t i = 0; i < P.n_rows; i++)
+            if (w.kinds[i] == WK_MUL && is_row(w.ra[i]) && is_row(w.rb[i])) {
+                uses[w.ra[i] & WREF_MASK]++;
+                if (w.rb[i] != w.ra[i]) uses[w.rb[i] & WREF_MASK]++;
+            }
+        const uint32_t NONE = 0xffffffffu;
+        std::vector<uint32_t> shadow_of(P.n_rows, NONE);
+        uint32_t next_shadow = (uint32_t)P.n_rows;
+        for (int phase = 0; phase < 2; phase++) {
+            const uint32_t first = next_shadow;
+            for (size_t i = phase_lo[phase]; i < phase_hi[phase]; i++) {
+                const uint32_t a = w.ra[i], b = w.rb[i];
+                if (w.kinds[i] != WK_MUL) { xrows[phase].push_back(XRow{w.kinds[i], (uint32_t)i, a, b}); continue; }
+                if (a == cst(WC_ONE) || b == cst(WC_ONE)) {  // x * 1: a copy
+                    xrows[phase].push_back(XRow{WK_ADD, (uint32_t)i, a == cst(WC_ONE) ? b : a, cst(WC_ZERO)});
+                    continue;
+                }
+                if (!is_row(a)) { xrows[phase].push_back(XRow{WK_MUL, (uint32_t)i, times_r(a), b}); continue; }
+                if (!is_row(b)) { xrows[phase].push_back(XRow{WK_MUL, (uint32_t)i, times_r(b), a}); continue; }
+                const uint32_t ia = a & WREF_MASK, ib = b & WREF_MASK;
+                uint32_t left = NONE, right = 0;
+                if (shadow_of[ia] != NONE) { left = shadow_of[ia]; right = b; }
+                else if (shadow_of[ib] != NONE) { left = shadow_of[ib]; right = a; }
+                else {
+                    const bool take_a = uses[ia] >= uses[ib];
+                    const uint32_t x = take_a ? ia : ib;
+                    shadow_of[x] = next_shadow++;
+                    xrows[phase].push_back(XRow{WK_MUL, shadow_of[x], cst(WC_R2), WREF_ROW | x});
+                    left = shadow_of[x]; right = take_a ? b : a;
+                }
+                xrows[phase].push_back(XRow{WK_MUL, (uint32_t)i, WREF_ROW | left, right});
+            }
+            P.n_shadow[phase] = next_shadow - first;
+        }
+        P.n_ext = next_shadow;
+    }
+    // row references share their word with the row-cache fields: 18 bits of row number
+    if (P.n_ext > (size_t)WROW_MASK + 1) { P.error = "witness trace has more rows than an operand reference can name"; return P; }
+
     // level scheduling per phase
-    std::vector<uint32_t> level(P.n_rows, 0);
-    auto lvl = [&](uint32_t ref) -> uint32_t { return (ref >> 30) == 0 ? level[ref & WREF_MASK] + 1 : 0; };
+    std::vector<uint32_t> level(P.n_ext, 0);
     for (int phase = 0; phase < 2; phase++) {
-        size_t lo = phase == 0 ? 0 : P.gen_start + 12, hi = phase == 0 ? P.gen_start : P.n_rows;
+        const std::vector<XRow>& X = xrows[phase];
+        const size_t nx = X.size();
+        std::vector<int32_t> local(P.n_ext, -1);  // position in X of the rows this phase makes
+        for (size_t q = 0; q < nx; q++) local[X[q].id] = (int32_t)q;
+        // rows of the other phase (and generator rows) are complete before this phase starts
+        auto in_phase = [&](uint32_t ref) { return (ref >> 30) == 0 && local[ref & WREF_MASK] >= 0; };
         uint32_t maxl = 0;
-        for (size_t i = lo; i < hi; i++) {
-            uint32_t l = std::max(lvl(w.ra[i]), lvl(w.rb[i]));
-            // rows of the other phase (and generator rows) are complete before this phase starts
-            auto in_phase = [&](uint32_t ref) { return (ref >> 30) == 0 && (ref & WREF_MASK) >= lo && (ref & WREF_MASK) < hi; };
-            uint32_t la = in_phase(w.ra[i]) ? level[w.ra[i] & WREF_MASK] + 1 : 0;
-            uint32_t lb = in_phase(w.rb[i]) ? level[w.rb[i] & WREF_MASK] + 1 : 0;
-            l = std::max(la, lb);
-            level[i] = l;
-            maxl = std::max(maxl, l);
+        for (size_t q = 0; q < nx; q++) {  // (X is in an order in which every row comes after the rows it reads)
+            const uint32_t la = in_phase(X[q].a) ? level[X[q].a & WREF_MASK] + 1 : 0;
+            const uint32_t lb = in_phase(X[q].b) ? level[X[q].b & WREF_MASK] + 1 : 0;
+            level[X[q].id] = std::max(la, lb);
+            maxl = std::max(maxl, level[X[q].id]);
         }
         // Which level a row runs in.  The lanes of a proof take a level's rows `group` at a time, and a group that
         // holds one product costs as much as a full group of products, so rows that can wait are held back until
         // they fill a group: every row has a latest level (the one before its first consumer's latest level), a row
         // at its latest level must run, and the others ready by then fill that group up, or run when a whole group
         // of them is ready.  Products first in every level, then the rest, so that few groups hold both.
-        std::vector<std::vector<uint32_t>> by(maxl + 1);
-        if (group <= 1) {
-            for (size_t i = lo; i < hi; i++) by[level[i]].push_back((uint32_t)i);
-        } else {
-            auto in_phase = [&](uint32_t ref) { return (ref >> 30) == 0 && (ref & WREF_MASK) >= lo && (ref & WREF_MASK) < hi; };
-            std::vector<uint32_t> late(hi - lo, maxl), npred(hi - lo, 0), ready_at(hi - lo, 0);
-            std::vector<std::vector<uint32_t>> users(hi - lo);
-            for (size_t i = lo; i < hi; i++) {
-                uint32_t refs[2] = {w.ra[i], w.rb[i]};
+        std::vector<std::vector<uint32_t>> by(maxl + 1);  // positions in X
+        if (P.rounds) {
+            // Rounds in row order.  X is in row order (a shadow row right before the first product that needs it), so
+            // the position in X is the priority: a round takes the ready operations of one kind with the lowest
+            // positions.  The other operations go first whenever fewer than `group` products are ready or their first
+            // is earlier in the trace than the first ready product: they are cheap (a round costs what its dearest
+            // operation costs), they make products ready, and the sums that follow four products in the trace then
+            // run right behind them, so that the two halves of a 128-byte line of the trace are written a round or two
+            // apart, while the line is still in the L2 cache (in dependency levels the sums of an Fq12 product come up to
+            // six levels after its 144 products, the half-written lines leave the cache in between, and the trace's
+            // bytes reach memory at half the rate a sequential writer gets).
+            by.clear();
+            std::vector<uint32_t> npred(nx, 0);
+            std::vector<std::vector<uint32_t>> users(nx);
+            for (size_t q = 0; q < nx; q++) {
+                const uint32_t refs[2] = {X[q].a, X[q].b};
                 for (int k = 0; k < (refs[0] == refs[1] ? 1 : 2); k++)
-                    if (in_phase(refs[k])) { users[(refs[k] & WREF_MASK) - lo].push_back((uint32_t)i); npred[i - lo]++; }
+                    if (in_phase(refs[k])) { users[local[refs[k] & WREF_MASK]].push_back((uint32_t)q); npred[q]++; }
             }
-            for (size_t i = hi; i-- > lo;)
-                for (uint32_t u : users[i - lo]) late[i - lo] = std::min(late[i - lo], late[u - lo] - 1);
+            typedef std::priority_queue<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> MinQ;
+            MinQ ready[2];  // products, others
+            for (size_t q = 0; q < nx; q++) if (!npred[q]) ready[X[q].kind == WK_MUL ? 0 : 1].push((uint32_t)q);
+            size_t done = 0;
+            while (!ready[0].empty() || !ready[1].empty()) {
+                int k = 0;
+                if (ready[0].empty()) k = 1;
+                else if (!ready[1].empty() && (ready[0].size() < (size_t)group || ready[1].top() < ready[0].top())) k = 1;
+                std::vector<uint32_t> round;
+                while (round.size() < (size_t)group && !ready[k].empty()) { round.push_back(ready[k].top()); ready[k].pop(); }
+                for (uint32_t q : round)
+                    for (uint32_t u : users[q])
+                        if (--npred[u] == 0) ready[X[u].kind == WK_MUL ? 0 : 1].push(u);
+                done += round.size();
+                by.push_back(std::move(round));
+            }
+            if (done != nx) { P.error = "witness round scheduling left rows over"; return P; }
+        } else if (group <= 1) {
+            for (size_t q = 0; q < nx; q++) by[level[X[q].id]].push_back((uint32_t)q);
+        } else {
+            std::vector<uint32_t> late(nx, maxl), npred(nx, 0), ready_at(nx, 0);
+            std::vector<std::vector<uint32_t>> users(nx);
+            for (size_t q = 0; q < nx; q++) {
+                const uint32_t refs[2] = {X[q].a, X[q].b};
+                for (int k = 0; k < (refs[0] == refs[1] ? 1 : 2); k++)
+                    if (in_phase(refs[k])) { users[local[refs[k] & WREF_MASK]].push_back((uint32_t)q); npred[q]++; }
+            }
+            for (size_t q = nx; q-- > 0;)
+                for (uint32_t u : users[q]) late[q] = std::min(late[q], late[u] - 1);
             std::vector<std::vector<uint32_t>> arrives(maxl + 2);
-            for (size_t i = lo; i < hi; i++) if (!npred[i - lo]) arrives[0].push_back((uint32_t)i);
+            for (size_t q = 0; q < nx; q++) if (!npred[q]) arrives[0].push_back((uint32_t)q);
             std::vector<uint32_t> pool[2];  // waiting rows: products, others
             for (uint32_t l = 0; l <= maxl; l++) {
-                for (uint32_t i : arrives[l]) pool[w.kinds[i] == WK_MUL ? 0 : 1].push_back(i);
+                for (uint32_t q : arrives[l]) pool[X[q].kind == WK_MUL ? 0 : 1].push_back(q);
                 for (int k = 0; k < 2; k++) {
                     auto& pl = pool[k];
-                    std::stable_sort(pl.begin(), pl.end(), [&](uint32_t x, uint32_t y) { return late[x - lo] < late[y - lo]; });
+                    std::stable_sort(pl.begin(), pl.end(), [&](uint32_t x, uint32_t y) { return late[x] < late[y]; });
                     size_t must = 0;
-                    while (must < pl.size() && late[pl[must] - lo] <= l) must++;
+                    while (must < pl.size() && late[pl[must]] <= l) must++;
                     size_t take = must ? (must + group - 1) / group * group : pl.size() / group * group;
                     take = std::min(take, pl.size());
-                    for (size_t q = 0; q < take; q++) {
-                        const uint32_t i = pl[q];
-                        by[l].push_back(i);
-                        for (uint32_t u : users[i - lo]) {
-                            ready_at[u - lo] = std::max(ready_at[u - lo], l + 1);
-                            if (--npred[u - lo] == 0) arrives[ready_at[u - lo]].push_back(u);
+                    for (size_t t = 0; t < take; t++) {
+                        const uint32_t q = pl[t];
+                        by[l].push_back(q);
+                        for (uint32_t u : users[q]) {
+                            ready_at[u] = std::max(ready_at[u], l + 1);
+                            if (--npred[u] == 0) arrives[ready_at[u]].push_back(u);
                         }
                     }
                     pl.erase(pl.begin(), pl.begin() + take);
@@ -391,7 +483,7 @@ WitnessProgram build_program(int group) {
         }
         P.level_start[phase].push_back(0);
         for (auto& rows : by) {
-            for (uint32_t i : rows) P.ops[phase].push_back(WitnessOp{i | ((uint32_t)w.kinds[i] << 28), w.ra[i], w.rb[i]});
+            for (uint32_t q : rows) P.ops[phase].push_back(WitnessOp{X[q].id | ((uint32_t)X[q].kind << 28), X[q].a, X[q].b});
             P.level_start[phase].push_back((uint32_t)P.ops[phase].size());
         }
         if (getenv("BLS381_WIT_STATS")) {  // dependency-level widths
@@ -400,16 +492,16 @@ WitnessProgram build_program(int group) {
                 size_t wd = rows.size();
                 hist[wd <= 4 ? 0 : wd <= 8 ? 1 : wd <= 16 ? 2 : wd <= 32 ? 3 : wd <= 64 ? 4 : wd <= 128 ? 5 : wd <= 256 ? 6 : 7]++;
             }
-            fprintf(stderr, "witness phase %d: %zu rows in %zu levels; widths <=4:%zu <=8:%zu <=16:%zu <=32:%zu <=64:%zu <=128:%zu <=256:%zu more:%zu\n",
-                    phase, hi - lo, by.size(), hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
-            size_t iters = 0, with_mul = 0, with_lin = 0, mixed = 0;
+            fprintf(stderr, "witness phase %d: %zu operations (%zu of them shadow rows) in %zu levels; widths <=4:%zu <=8:%zu <=16:%zu <=32:%zu <=64:%zu <=128:%zu <=256:%zu more:%zu\n",
+                    phase, nx, P.n_shadow[phase], by.size(), hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
+            size_t iters = 0, with_mul = 0, with_lin = 0, mixed = 0, n_mul = 0;
             for (auto& rows : by)
                 for (size_t j = 0; j < rows.size(); j += 16) {
                     bool m = false, l = false;
-                    for (size_t q = j; q < std::min(rows.size(), j + (size_t)16); q++) (w.kinds[rows[q]] == WK_MUL ? m : l) = true;
+                    for (size_t t = j; t < std::min(rows.size(), j + (size_t)16); t++) { (X[rows[t]].kind == WK_MUL ? m : l) = true; n_mul += X[rows[t]].kind == WK_MUL; }
                     iters++; with_mul += m; with_lin += l; mixed += m && l;
                 }
-            fprintf(stderr, "  sixteen rows at a time: %zu groups, %zu with a product, %zu with other rows, %zu with both\n", iters, with_mul, with_lin, mixed);
+            fprintf(stderr, "  sixteen rows at a time: %zu groups, %zu with a product (%zu products), %zu with other rows, %zu with both\n", iters, with_mul, n_mul, with_lin, mixed);
         }
     }
     return P;
@@ -435,34 +527,50 @@ static std::vector<WitnessOp> plan_in_order(const WitnessProgram& P, int phase, 
     for (size_t l = 0; l + 1 < ls.size(); l++)
         for (uint32_t i = ls[l]; i < ls[l + 1]; i += (uint32_t)lpp, it++)
             for (uint32_t j = i; j < std::min(i + (uint32_t)lpp, ls[l + 1]); j++) iter_of[j] = it;
-    std::vector<std::vector<uint32_t>> uses(P.n_rows);  // iterations that read a row, ascending
+    std::vector<std::vector<uint32_t>> uses(P.n_ext);  // iterations that read a row, ascending
     for (size_t j = 0; j < ops.size(); j++) {
         uint32_t* refs[2] = {&ops[j].a, &ops[j].b};
         for (int k = 0; k < n_operands(ops[j]); k++)
             if ((*refs[k] >> 30) == 0) { uses[*refs[k] & WROW_MASK].push_back(iter_of[j]); reads++; }
     }
-    if (cache_rows > 0) {
-        std::vector<size_t> cursor(P.n_rows, 0);
+    // round in which this phase makes a row (-1: before the phase), and the last round before the current one in which
+    // the wave loads from global memory
+    std::vector<int64_t> made_at(P.n_ext, -1);
+    for (size_t j = 0; j < ops.size(); j++) made_at[ops[j].dst & WROW_MASK] = iter_of[j];
+    int64_t last_wait = -1;
+    size_t drains = 0;
+    {
+        std::vector<size_t> cursor(P.n_ext, 0);
         auto next_use = [&](uint32_t row, uint32_t now) -> uint32_t {
             size_t& c = cursor[row];
             while (c < uses[row].size() && uses[row][c] <= now) c++;
             return c < uses[row].size() ? uses[row][c] : 0xffffffffu;
         };
-        std::vector<int> slot_of(P.n_rows, -1);
+        std::vector<int> slot_of(P.n_ext, -1);
         std::vector<int64_t> row_in(cache_rows, -1), placed_at(cache_rows, -1);
         for (size_t j = 0; j < ops.size();) {
             size_t e = j;
             while (e < ops.size() && iter_of[e] == iter_of[j]) e++;
             const uint32_t now = iter_of[j];
+            bool reads_memory = false;
             for (size_t q = j; q < e; q++) {
                 uint32_t* refs[2] = {&ops[q].a, &ops[q].b};
                 for (int k = 0; k < n_operands(ops[q]); k++) {
-                    if ((*refs[k] >> 30) != 0) continue;
-                    const int sl = slot_of[*refs[k] & WROW_MASK];
-                    if (sl >= 0) { *refs[k] |= WCACHE_FLAG | ((uint32_t)sl << WCACHE_SLOT_SHIFT); hits++; }
+                    if ((*refs[k] >> 30) != 0) { reads_memory = true; continue; }
+                    const uint32_t row = *refs[k] & WROW_MASK;
+                    const int sl = slot_of[row];
+                    if (sl >= 0) { *refs[k] |= WCACHE_FLAG | ((uint32_t)sl << WCACHE_SLOT_SHIFT); hits++; continue; }
+                    reads_memory = true;
+                    // Without a barrier between rounds, a row comes from global memory only if the wave has waited for
+                    // its memory operations since the row was stored: it waits whenever it loads from memory (its
+                    // memory operations finish in the order it issued them), so a load issued in a later round than
+                    // such a wait, itself later than the store's round, finds the row.  Where the plan cannot show that
+                    // wait, the operation asks for one before its reads.
+                    if (P.rounds && made_at[row] >= 0 && !(made_at[row] < last_wait)) { ops[q].dst |= WDRAIN_FLAG; drains++; }
                 }
             }
-            for (size_t q = j; q < e; q++) {
+            if (reads_memory) last_wait = (int64_t)now;
+            for (size_t q = j; q < e && cache_rows > 0; q++) {
                 const uint32_t row = ops[q].dst & WROW_MASK;
                 const uint32_t nu = next_use(row, now);
                 if (nu == 0xffffffffu) continue;
@@ -486,6 +594,7 @@ static std::vector<WitnessOp> plan_in_order(const WitnessProgram& P, int phase, 
     }
     if (reads_out) *reads_out = reads;
     if (hits_out) *hits_out = hits;
+    if (getenv("BLS381_WIT_STATS")) fprintf(stderr, "witness phase %d plan: %zu operations wait for earlier stores before their reads\n", phase, drains);
     return ops;
 }
 
@@ -536,7 +645,7 @@ std::vector<WitnessOp> plan_row_cache(const WitnessProgram& P, int phase, int lp
                 for (uint32_t j = ls[l]; j < ls[l + 1]; j++)
                     if (class_of(planned[j]) == c) {
                         WitnessOp o = planned[j];
-                        o.dst &= ~plan_bits;
+                        o.dst &= ~(plan_bits | WDRAIN_FLAG);
                         if ((o.a >> 30) == 0) o.a &= ~plan_bits;
                         if ((o.b >> 30) == 0) o.b &= ~plan_bits;
                         order.push_back(o);
@@ -555,8 +664,9 @@ const WitnessProgram& witness_program() {
     static std::mutex mu;
     static std::map<int, std::unique_ptr<WitnessProgram>> built;
     const int group = env_group();
+    const char* sched = getenv("BLS381_WIT_SCHED");
     std::lock_guard<std::mutex> g(mu);
-    auto& p = built[group];
+    auto& p = built[group * 2 + (sched && std::string(sched) == "levels" ? 1 : 0)];
     if (!p) p.reset(new WitnessProgram(build_program(group)));
     return *p;
 }
@@ -584,28 +694,41 @@ __device__ __forceinline__ void w_load(const u32* base, u32 ref, const u32* T, c
 // global memory, which always holds every finished row.  The lanes of a proof sit in one wave (lpp divides 64) and
 // a wave executes its LDS instructions in order, all lanes together: every lane's reads of an iteration precede
 // every lane's writes of it, as the plan assumes.
-// (Compiled for five waves per SIMD, 96 registers with two of them spilled, so that LDS and not the register file
-// decides how many workgroups a CU holds; measured +2.5 % at 48 cache rows against the 112-register build.)
+// Rows from `rows` on are the shadow rows (WitnessProgram::ops): `shadow` holds n_shadow of them per proof.
+// (Compiled for five waves per SIMD, 96 registers, so that LDS and not the register file decides how many workgroups a
+// CU holds.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void witness_kernel(const WitnessOp* ops, const u32* level_start, int nlevels,
-                                                      u32* trace, size_t rows, const u32* consts, const u32* inputs,
-                                                      int lpp, int nproofs, int cache_rows) {
+                                                      u32* trace, size_t rows, u32* shadow, size_t n_shadow, const u32* consts,
+                                                      const u32* inputs, int lpp, int nproofs, int cache_rows, int level_barriers) {
     extern __shared__ uint4 wcache[];
     const int proof = blockIdx.x * (blockDim.x / lpp) + threadIdx.x / lpp;
     const int sub = threadIdx.x % lpp;
     const bool live = proof < nproofs;
     u32* T = trace + (size_t)(live ? proof : 0) * rows * 12;
-    const u32* in = inputs + (size_t)(live ? proof : 0) * 6 * 12;
+    u32* S = shadow + (size_t)(live ? proof : 0) * n_shadow * 12;
+    auto row_at = [&](u32 idx) { return idx < rows ? T + (size_t)idx * 12 : S + (size_t)(idx - (u32)rows) * 12; };
+    const u32* in = inputs + (size_t)(live ? proof : 0) * WIN_TOTAL * 12;
     const u32 P[12] = BLS381_P_LIMBS;
     uint4* cdata = wcache + (size_t)(threadIdx.x / lpp) * cache_rows * 3;  // this proof's entries: 3 uint4 each
     auto load = [&](u32 ref, u32* x) {
-        if ((ref >> 30) == 0 && (ref & WCACHE_FLAG)) {
-            const uint4* q = cdata + (size_t)((ref >> WCACHE_SLOT_SHIFT) & WCACHE_SLOT_MASK) * 3;
-            uint4 a = q[0], b = q[1], c = q[2];
-            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
-            x[8] = c.x; x[9] = c.y; x[10] = c.z; x[11] = c.w;
+        const u32 sp = ref >> 30, idx = ref & WROW_MASK;
+        // Two separate paths with the address space in the pointer's type and a plain vector as the loaded type: copies
+        // of uint4 structures go through generic pointers, the two paths then merge into one generic load (address
+        // chosen by a select), and generic loads count against both memory counters, so that every later wait is a
+        // wait for everything, and take the long way to LDS.
+        typedef u32 v4u __attribute__((ext_vector_type(4)));
+        v4u a, b, c;
+        if (sp == 0 && (ref & WCACHE_FLAG)) {
+            const __attribute__((address_space(3))) v4u* q =
+                (const __attribute__((address_space(3))) v4u*)(cdata + (size_t)((ref >> WCACHE_SLOT_SHIFT) & WCACHE_SLOT_MASK) * 3);
+            a = q[0]; b = q[1]; c = q[2];
         } else {
-            w_load(T, ref, T, consts, in, x);
+            const u32* g = sp == 0 ? row_at(idx) : (sp == 1 ? consts : in) + (size_t)idx * 12;
+            const __attribute__((address_space(1))) v4u* q = (const __attribute__((address_space(1))) v4u*)(uintptr_t)g;
+            a = q[0]; b = q[1]; c = q[2];
         }
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+        x[8] = c.x; x[9] = c.y; x[10] = c.z; x[11] = c.w;
     };
     // A lane's operation is fetched one round ahead, before the round's results are stored: the wave's memory
     // operations finish in order, so a fetch issued behind the stores would wait for them as well.
@@ -624,6 +747,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 if (j < (same ? hi : next_hi)) nxt = ops[j];
             }
             const u32 kind = op.dst >> 28, row = op.dst & WROW_MASK;
+            // (rounds without barriers: a read the plan could not place behind an earlier wait of this wave)
+            if (__any(has && (op.dst & WDRAIN_FLAG))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             u32 a[12], b[12], r[12];
             if (has) {
             load(op.a, a);
@@ -634,8 +759,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 r[0] = v0.x; r[1] = v0.y; r[2] = v0.z; r[3] = v0.w; r[4] = v1.x; r[5] = v1.y; r[6] = v1.z; r[7] = v1.w;
                 r[8] = v2.x; r[9] = v2.y; r[10] = v2.z; r[11] = v2.w;
             } else if (kind == WK_MUL) {
+                // a = (the left factor) * 2^392, b canonical: one Montgomery product on 28-bit digits is the canonical
+                // product (every multiply-accumulate a single instruction; the Barrett product on 12 x 32-bit limbs
+                // that this replaces took 336 multiply-accumulates with an add-with-carry behind each)
                 load(op.b, b);
-                fp_mul_canon(a, b, r);  // rows are canonical values: no Montgomery factor to carry
+                u32 da[D28], db[D28], dr[D28];
+                unpack28(a, da);
+                unpack28(b, db);
+                fp28_mul(da, db, dr);
+                canon28(dr);
+                pack28(dr, r);
             } else if (kind == WK_ADD) {
                 load(op.b, b);
                 carry_t c;
@@ -664,7 +797,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 #pragma unroll
                 for (int k = 1; k < 12; k++) r[k] = subb_co(P[k] & m, a[k], c);
             }
-            uint4* d = reinterpret_cast<uint4*>(T + (size_t)row * 12);
+            uint4* d = reinterpret_cast<uint4*>(row_at(row));
             d[0] = make_uint4(r[0], r[1], r[2], r[3]);
             d[1] = make_uint4(r[4], r[5], r[6], r[7]);
             d[2] = make_uint4(r[8], r[9], r[10], r[11]);
@@ -682,20 +815,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
+        if (level_barriers) __syncthreads();  // (uniform)
     }
 }
 
-// inputs: Montgomery {px,py} and {qx0,qx1,qy0,qy1} -> canonical, 6 Fq per proof
-__global__ void witness_inputs_kernel(const u32* g1, const u32* g2, u32* inputs, int n) {
+// inputs: Montgomery {px,py} and {qx0,qx1,qy0,qy1} -> per proof 6 canonical values, then the same times 2^392
+__global__ void witness_inputs_kernel(const u32* g1, const u32* g2, const u32* consts, u32* inputs, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * 6) return;
-    int e = i / 6, f = i % 6;
+    if (i >= n * WIN_TOTAL) return;
+    int e = i / WIN_TOTAL, f = i % WIN_TOTAL % WIN_COUNT;
+    const bool times_r = i % WIN_TOTAL >= WIN_COUNT;
     const u32* src = f < 2 ? g1 + ((size_t)e * 2 + f) * 12 : g2 + ((size_t)e * 4 + (f - 2)) * 12;
-    u32 a[12], one[12] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, r[12];
-    for (int k = 0; k < 12; k++) a[k] = src[k];
-    fp_mul(a, one, r);
-    for (int k = 0; k < 12; k++) inputs[(size_t)i * 12 + k] = r[k];
+    // x * 2^384 times 1, or times 2^392, divided by 2^384
+    const u32* factor = consts + (size_t)(times_r ? WC_TIMES_R + WC_ONE : WC_ONE) * 12;
+    u32 a[12], k[12], r[12];
+    for (int l = 0; l < 12; l++) { a[l] = src[l]; k[l] = factor[l]; }
+    fp_mul(a, k, r);
+    for (int l = 0; l < 12; l++) inputs[(size_t)i * 12 + l] = r[l];
 }
 // x[e][k] = trace row refs[k] of proof e   /   trace generator rows = inv[e][k]
 __global__ void witness_gather_kernel(const u32* trace, size_t rows, const u32* refs, u32* x, int n) {
@@ -726,7 +862,7 @@ __global__ void witness_aux_kernel(const WitnessOp* ops, int nops, const u32* mu
     const WitnessOp op = ops[t % nops];
     const u32 kind = op.dst >> 28, row = op.dst & WROW_MASK;
     const u32* T = trace + (size_t)proof * rows * 12;
-    const u32* in = inputs + (size_t)proof * 6 * 12;
+    const u32* in = inputs + (size_t)proof * WIN_TOTAL * 12;
     const u32 P[12] = BLS381_P_LIMBS;
     u32 a[12], b[12], r[12];
     w_load(T, op.a, T, consts, in, a);
@@ -793,21 +929,8 @@ __global__ void witness_aux_kernel(const WitnessOp* ops, int nops, const u32* mu
 }
 
 static void fill_wconsts(std::vector<uint32_t>& c) {
-    c.assign((size_t)WC_COUNT * 12, 0);
-    c[(size_t)WC_ONE * 12] = 1;
-    c[(size_t)WC_FOUR * 12] = 4;
-    std::memcpy(&c[(size_t)WC_TWO_INV * 12], BLS381_TWO_INV_CANON, 48);
-    const uint32_t* f1[5][2] = {{BLS381_FROB1_1_C0_CANON, BLS381_FROB1_1_C1_CANON}, {BLS381_FROB1_2_C0_CANON, BLS381_FROB1_2_C1_CANON},
-                                {BLS381_FROB1_3_C0_CANON, BLS381_FROB1_3_C1_CANON}, {BLS381_FROB1_4_C0_CANON, BLS381_FROB1_4_C1_CANON},
-                                {BLS381_FROB1_5_C0_CANON, BLS381_FROB1_5_C1_CANON}};
-    const uint32_t* f2[5][2] = {{BLS381_FROB2_1_C0_CANON, BLS381_FROB2_1_C1_CANON}, {BLS381_FROB2_2_C0_CANON, BLS381_FROB2_2_C1_CANON},
-                                {BLS381_FROB2_3_C0_CANON, BLS381_FROB2_3_C1_CANON}, {BLS381_FROB2_4_C0_CANON, BLS381_FROB2_4_C1_CANON},
-                                {BLS381_FROB2_5_C0_CANON, BLS381_FROB2_5_C1_CANON}};
-    for (int i = 0; i < 5; i++)
-        for (int j = 0; j < 2; j++) {
-            std::memcpy(&c[(size_t)(WC_FROB1_BASE + 2 * i + j) * 12], f1[i][j], 48);
-            std::memcpy(&c[(size_t)(WC_FROB2_BASE + 2 * i + j) * 12], f2[i][j], 48);
-        }
+    static_assert(sizeof(BLS381_WITNESS_CONST) == (size_t)WC_TOTAL * 48, "constant table and WitnessConst disagree");
+    c.assign(&BLS381_WITNESS_CONST[0][0], &BLS381_WITNESS_CONST[0][0] + (size_t)WC_TOTAL * 12);
 }
 
 #define WCHK(x)                                                                  \
@@ -831,16 +954,16 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
                        uint32_t* trace, std::string& err, bool on_device, const WitnessAux* aux) {
     const WitnessProgram& P = witness_program();
     if (!P.error.empty()) { err = P.error; return -1; }
-    if (uploaded_ && prog_group_ != P.group) {  // another level assignment than the one uploaded
+    if (uploaded_ && prog_group_ != P.group * 2 + (P.rounds ? 1 : 0)) {  // another level assignment than the one uploaded
         WCHK(hipStreamSynchronize(stream));
         release();
     }
     if (!uploaded_) {
         release();  // an earlier upload that failed half-way leaves nothing behind
         for (int ph = 0; ph < 2; ph++) {
-            WCHK(hipMalloc((void**)&d_ops_[ph], P.ops[ph].size() * sizeof(WitnessOp)));
+            WCHK(hipMalloc((void**)&d_ops_[ph], P.circuit_ops[ph].size() * sizeof(WitnessOp)));
             WCHK(hipMalloc((void**)&d_levels_[ph], P.level_start[ph].size() * 4));
-            WCHK(hipMemcpy(d_ops_[ph], P.ops[ph].data(), P.ops[ph].size() * sizeof(WitnessOp), hipMemcpyHostToDevice));
+            WCHK(hipMemcpy(d_ops_[ph], P.circuit_ops[ph].data(), P.circuit_ops[ph].size() * sizeof(WitnessOp), hipMemcpyHostToDevice));
             WCHK(hipMemcpy(d_levels_[ph], P.level_start[ph].data(), P.level_start[ph].size() * 4, hipMemcpyHostToDevice));
         }
         std::vector<uint32_t> wc;
@@ -852,7 +975,7 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         WCHK(hipMalloc((void**)&d_mul_index_, P.n_rows * 4));
         WCHK(hipMemcpy(d_mul_index_, P.mul_index.data(), P.n_rows * 4, hipMemcpyHostToDevice));
         uploaded_ = true;
-        prog_group_ = P.group;
+        prog_group_ = P.group * 2 + (P.rounds ? 1 : 0);
     }
     // Sixteen lanes per proof, four proofs per one-wave workgroup: dependency levels are about 35 rows wide
     // (a third of them at most 16), so wider groups mostly idle at their barriers, and the kernel hides its load
@@ -868,7 +991,7 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
     // tuning overrides; out-of-range values are errors (a stride of 0 would never advance the loop below)
     if (const char* e = getenv("BLS381_WIT_CH")) {
         const long v = atol(e);
-        if (v < 1 || v > 16384) { err = "BLS381_WIT_CH must be in 1..16384"; return -1; }
+        if (v < 1 || v > 32768) { err = "BLS381_WIT_CH must be in 1..32768"; return -1; }
         CH = (size_t)v;
     }
     if (const char* e = getenv("BLS381_WIT_BLOCK")) block = atoi(e);
@@ -902,7 +1025,9 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         size_t tbytes = (size_t)m * P.n_rows * 48;
         if (!on_device) WCHK(ensure(d_trace_, trace_bytes_, tbytes));
         u32* const d_trace_m = on_device ? trace + off * P.n_rows * 12 : (u32*)d_trace_;
-        WCHK(ensure(d_inputs_, inputs_bytes_, (size_t)m * 6 * 48));
+        WCHK(ensure(d_inputs_, inputs_bytes_, (size_t)m * WIN_TOTAL * 48));
+        const size_t n_shadow = P.n_shadow[0] + P.n_shadow[1];
+        WCHK(ensure(d_shadow_, shadow_bytes_, (size_t)m * n_shadow * 48 + 48));
         WCHK(ensure(d_x_, x_bytes_, (size_t)m * 576 * 2));
         WCHK(ensure(d_g_, g_bytes_, (size_t)m * 288));
         u32* d_g1 = (u32*)d_g_;
@@ -910,10 +1035,10 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         const hipMemcpyKind in_kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
         WCHK(hipMemcpyAsync(d_g1, g1 + off * 12, (size_t)m * 96, in_kind, stream));
         WCHK(hipMemcpyAsync(d_g2, g2 + off * 24, (size_t)m * 192, in_kind, stream));
-        hipLaunchKernelGGL(witness_inputs_kernel, dim3((m * 6 + 63) / 64), dim3(64), 0, stream, d_g1, d_g2, (u32*)d_inputs_, m);
+        hipLaunchKernelGGL(witness_inputs_kernel, dim3((m * WIN_TOTAL + 63) / 64), dim3(64), 0, stream, d_g1, d_g2, (const u32*)d_consts_, (u32*)d_inputs_, m);
         WCHK(hipGetLastError());
         hipLaunchKernelGGL(witness_kernel, dim3((m + per_block - 1) / per_block), dim3(block), cache_bytes, stream, d_plan_[0], d_levels_[0],
-                           (int)P.level_start[0].size() - 1, d_trace_m, P.n_rows, d_consts_, (const u32*)d_inputs_, lpp, m, cache_rows);
+                           (int)P.level_start[0].size() - 1, d_trace_m, P.n_rows, (u32*)d_shadow_, n_shadow, d_consts_, (const u32*)d_inputs_, lpp, m, cache_rows, P.rounds ? 0 : 1);
         WCHK(hipGetLastError());
         u32* d_x = (u32*)d_x_;
         u32* d_inv = d_x + (size_t)m * 144;
@@ -926,7 +1051,7 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
                            P.gen_start, d_inv, m);
         WCHK(hipGetLastError());
         hipLaunchKernelGGL(witness_kernel, dim3((m + per_block - 1) / per_block), dim3(block), cache_bytes, stream, d_plan_[1], d_levels_[1],
-                           (int)P.level_start[1].size() - 1, d_trace_m, P.n_rows, d_consts_, (const u32*)d_inputs_, lpp, m, cache_rows);
+                           (int)P.level_start[1].size() - 1, d_trace_m, P.n_rows, (u32*)d_shadow_, n_shadow, d_consts_, (const u32*)d_inputs_, lpp, m, cache_rows, P.rounds ? 0 : 1);
         WCHK(hipGetLastError());
         if (aux && (aux->mul_quot || aux->carry || aux->inv_quot)) {
             const size_t n_mul = P.counts[WK_MUL];
@@ -947,9 +1072,9 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
             }
             if (d_cy) WCHK(hipMemsetAsync(d_cy, 0, (size_t)m * P.n_rows, stream));  // generator rows carry nothing
             for (int ph = 0; ph < 2; ph++) {
-                const long threads = (long)m * (long)P.ops[ph].size();
+                const long threads = (long)m * (long)P.circuit_ops[ph].size();
                 hipLaunchKernelGGL(witness_aux_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d_ops_[ph],
-                                   (int)P.ops[ph].size(), (const u32*)d_mul_index_, (const u32*)d_trace_m, P.n_rows, d_consts_,
+                                   (int)P.circuit_ops[ph].size(), (const u32*)d_mul_index_, (const u32*)d_trace_m, P.n_rows, d_consts_,
                                    (const u32*)d_inputs_, m, n_mul, d_mq, d_cy, d_iq);
                 WCHK(hipGetLastError());
             }
@@ -972,9 +1097,9 @@ void WitnessDevice::release() {
         d_levels_[ph] = nullptr;
     }
     plan_lpp_ = plan_rows_ = -1;
-    for (void* p : {(void*)d_consts_, (void*)d_inv_refs_, (void*)d_mul_index_, d_trace_, d_inputs_, d_x_, d_g_, d_aux_}) if (p) (void)hipFree(p);
-    d_consts_ = nullptr; d_inv_refs_ = nullptr; d_mul_index_ = nullptr; d_trace_ = d_inputs_ = d_x_ = d_g_ = d_aux_ = nullptr;
-    trace_bytes_ = inputs_bytes_ = x_bytes_ = g_bytes_ = aux_bytes_ = 0;
+    for (void* p : {(void*)d_consts_, (void*)d_inv_refs_, (void*)d_mul_index_, d_trace_, d_inputs_, d_x_, d_g_, d_aux_, d_shadow_}) if (p) (void)hipFree(p);
+    d_consts_ = nullptr; d_inv_refs_ = nullptr; d_mul_index_ = nullptr; d_trace_ = d_inputs_ = d_x_ = d_g_ = d_aux_ = d_shadow_ = nullptr;
+    trace_bytes_ = inputs_bytes_ = x_bytes_ = g_bytes_ = aux_bytes_ = shadow_bytes_ = 0;
     uploaded_ = false;
 }
 

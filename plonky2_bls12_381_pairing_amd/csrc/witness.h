@@ -23,11 +23,14 @@ namespace bls381 {
 enum WitnessKind : uint8_t { WK_ADD = 0, WK_SUB = 1, WK_MUL = 2, WK_NEG = 3, WK_INV = 4, WK_GEN = 5 };
 
 // operand reference: bits 30..31 = space (0 trace row, 1 constant, 2 circuit input), bits 0..17 = index.
+// Row indices from n_rows on name rows the kernel keeps beside the trace, in a buffer of its own (the products' left
+// operands, see WitnessProgram::n_shadow).
 // In the operations handed to the kernel (plan_row_cache) a row reference may also say that the row sits in the
 // proof's LDS row cache: bit 25 set, entry number in bits 18..24.  WitnessOp::dst carries the same fields for the
 // row an operation produces: bit 25 = the result is kept in the cache entry of bits 18..24 as well.
 enum { WREF_ROW = 0u << 30, WREF_CONST = 1u << 30, WREF_INPUT = 2u << 30, WREF_MASK = (1u << 30) - 1 };
-enum : uint32_t { WROW_MASK = (1u << 18) - 1, WCACHE_SLOT_SHIFT = 18, WCACHE_SLOT_MASK = 0x7f, WCACHE_FLAG = 1u << 25, WCACHE_MAX_ROWS = 128 };
+enum : uint32_t { WROW_MASK = (1u << 18) - 1, WCACHE_SLOT_SHIFT = 18, WCACHE_SLOT_MASK = 0x7f, WCACHE_FLAG = 1u << 25, WCACHE_MAX_ROWS = 128,
+                  WDRAIN_FLAG = 1u << 26 };  // in WitnessOp::dst: finish every earlier store before this operation's reads (see WitnessProgram::rounds)
 
 struct WitnessOp {
     uint32_t dst;   // row index (bits 0..17) | cache fields | kind << 28
@@ -40,15 +43,37 @@ enum WitnessConst {
     WC_FROB1_BASE = 4,   // + 2*(i-1) + {0,1}, i = 1..5
     WC_FROB2_BASE = 14,  // + 2*(i-1) + {0,1}, i = 1..5 (c1 = 0)
     WC_COUNT = 24,
+    WC_TIMES_R = 24,     // + k: constant k times 2^392 (a product's left operand, see WitnessProgram::n_shadow)
+    WC_R2 = 48,          // 2^784: the left operand that turns a canonical row into row * 2^392
+    WC_TOTAL = 49,
 };
+// circuit inputs per proof: 0..5 canonical {px, py, qx.c0, qx.c1, qy.c0, qy.c1}, 6..11 the same times 2^392
+enum { WIN_COUNT = 6, WIN_TOTAL = 12 };
 
 struct WitnessProgram {
     int group = 0;                        // rows of a level that run together, as the level assignment assumed (0: none)
+    // How the operations are arranged.  false: in dependency levels (no operation reads a row of its own level; the
+    // kernel ends a level with a barrier that also finishes its stores).  true: in rounds of at most `group` operations,
+    // each a "level" of its own in level_start, chosen in row order from what is ready, products and other operations
+    // in rounds of their own; a round may read what the round before it made, through the proof's LDS row cache, and
+    // no barrier separates rounds.  A row read from global memory must have been stored before an earlier wait of the
+    // wave for its memory operations: plan_row_cache marks the reads that would come too early with WDRAIN_FLAG.
+    bool rounds = false;
     size_t n_rows = 0;
     std::vector<uint8_t> kinds;           // per row
     size_t gen_start = 0;                 // first of the 12 generator-output rows
     uint32_t inv_input_refs[12];          // rows holding x (MyFq12 order) that Fq12InverseGenerator inverts
+    // What the kernel runs.  A product row is one Montgomery multiplication on 28-bit digits, left * right / 2^392, so
+    // its left operand has to be (a value) * 2^392: a constant or circuit input kept in that form as well, or a "shadow"
+    // row = 2^784 * (a trace row) / 2^392, made once by a product operation of its own and used by every product that
+    // has the row as a factor (an Fq12Target::mul makes 12 of them for its 144 + 10 products).  Shadow rows have the
+    // indices n_rows .. n_rows + n_shadow[0] + n_shadow[1] (phase 0's first) and live in a buffer beside the trace.
+    // A product by the constant one is a copy here (an addition of zero).
     std::vector<WitnessOp> ops[2];        // phase 0: rows before the generator output, phase 1: rows after
+    size_t n_shadow[2] = {0, 0};
+    size_t n_ext = 0;                     // n_rows + the shadow rows
+    // The circuit's operations themselves, one per row in row order (the auxiliary-value kernel reads these).
+    std::vector<WitnessOp> circuit_ops[2];
     std::vector<uint32_t> level_start[2]; // per phase, nlevels + 1 offsets into ops[phase]
     size_t counts[6] = {0, 0, 0, 0, 0, 0};
     std::vector<uint32_t> mul_index;      // per row: its ordinal among the mul rows (0xffffffff for other kinds)
@@ -93,6 +118,7 @@ class WitnessDevice {
     void* d_x_ = nullptr;      size_t x_bytes_ = 0;
     void* d_g_ = nullptr;      size_t g_bytes_ = 0;
     void* d_aux_ = nullptr;    size_t aux_bytes_ = 0;
+    void* d_shadow_ = nullptr; size_t shadow_bytes_ = 0;
     uint32_t* d_mul_index_ = nullptr;
 };
 

@@ -298,6 +298,25 @@ def test_full_batch_65536_against_c_oracle_and_bilinearity(ctx, CO):
     assert all(np.array_equal(prod[i], one) for i in range(m))
 
 
+def test_chained_final_exponentiation_on_ragged_batches(ctx, CO):
+    """Batches above 8,192 pairs take the hard part's squaring chains through the register-resident kernel and the
+    multiplications around them through six programs; below, one program does it all.  Ragged sizes just above the
+    switch (a last workgroup of the chain kernel with 1, 65 and 201 live elements): every output equals the same
+    inputs run in small batches through the single program, and a sample equals the CPU oracle."""
+    base = 48
+    ps, qs = H.random_pairs(base, 90210)
+    g1b, g2b = H.g1_array(ps), H.g2_array(qs)
+    for n in (8192 + 1, 8192 + 65, 8192 + 2048 + 201):
+        idx_p = (np.arange(n) * 11 + 3) % base
+        idx_q = (np.arange(n) // 5 + np.arange(n)) % base
+        g1, g2 = g1b[idx_p], g2b[idx_q]
+        out = ctx.pairing_batch(g1, g2)
+        small = np.concatenate([ctx.pairing_batch(g1[i:i + 4096], g2[i:i + 4096]) for i in range(0, n, 4096)])
+        assert np.array_equal(out, small), n
+        probe = np.array([0, 63, 64, 255, 256, 8191, 8192, n - 2, n - 1])
+        assert np.array_equal(out[probe], CO.pairing_batch(g1[probe], g2[probe])), n
+
+
 def test_batch_spanning_two_chunks(ctx, CO):
     """A batch larger than the library's 65,536-element working chunk (maximum-size edge): elements on
     both sides of the chunk boundary and the ragged tail against the CPU oracle, and the tail chunk
@@ -400,6 +419,28 @@ def test_witness_level_assignments(ctx, group, monkeypatch):
     assert np.array_equal(ctx.pairing_witness_batch(g1, g2), want)
     monkeypatch.delenv("BLS381_WIT_GROUP")
     assert np.array_equal(ctx.pairing_witness_batch(g1, g2), want)
+
+
+def test_witness_schedules_and_geometries_agree(ctx, monkeypatch):
+    """The kernel's operations run in rounds taken in row order, without barriers, reading what the rounds before made
+    from the proof's LDS row cache (the default), or in dependency levels with a barrier after each
+    (BLS381_WIT_SCHED=levels).  The trace bytes are the same in both, with a cache too small to hold what a round's
+    successor reads (rows then come back from global memory behind an explicit wait), without a cache, and at 32 and
+    8 lanes per proof; every row against the CPU replay."""
+    import witness_ref as W
+    ps, qs = H.random_pairs(6, 1717)
+    g1, g2 = H.g1_array(ps), H.g2_array(qs)
+    want = ctx.pairing_witness_batch(g1, g2)
+    tr, _ = W.pairing_witness(ps[3], qs[3])
+    assert np.array_equal(want[3], np.array([R.fq_to_u32_limbs(v) for _, v in tr.rows], dtype=np.uint32))
+    for env in ({"BLS381_WIT_SCHED": "levels"}, {"BLS381_WIT_CACHE": "3"}, {"BLS381_WIT_CACHE": "0"},
+                {"BLS381_WIT_LPP": "32", "BLS381_WIT_CACHE": "96"}, {"BLS381_WIT_LPP": "8", "BLS381_WIT_CACHE": "20"},
+                {"BLS381_WIT_SCHED": "levels", "BLS381_WIT_CACHE": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert np.array_equal(ctx.pairing_witness_batch(g1, g2), want), env
+        for k in env:
+            monkeypatch.delenv(k)
 
 
 def test_pairing_witness_auxiliary_values(ctx):
@@ -1223,7 +1264,7 @@ def _raw392(vals):
 def test_squaring_chain_kernel(ctx):
     """The kernel that runs the hard part's 63-squaring chains in registers (three waves per 64 elements, generated
     assembly): the six powers a^(2^k), k = 16, 48, 57, 60, 62, 63, it keeps against the oracle's plain squarings, for
-    batch sizes on both sides of a workgroup's 64 elements; their product is pow_native(a, BLS_X)."""
+    batch sizes on both sides of a wave's 64 and a workgroup's 256 elements; their product is pow_native(a, BLS_X)."""
     import ctypes as C
     from plonky2_bls12_381_pairing_amd import _lib
     xs = [R.myfq12_to_fq12(R.easy_part_native(R.myfq12_from_fq12(x))) for x in H.random_fq12(3, 6301)]   # cyclotomic subgroup
@@ -1242,7 +1283,7 @@ def test_squaring_chain_kernel(ctx):
         want.append(_raw392(row).reshape(-1))
     want = np.array(want)
     inv392 = R.fq_inv((1 << 392) % R.P)
-    for n in (1, 3, 64, 65, 200):
+    for n in (1, 3, 64, 65, 200, 256, 257, 833):     # (a workgroup is four groups of 64 elements)
         a = np.ascontiguousarray(_raw392([xs[i % 3] for i in range(n)]))
         out = np.zeros((n, 6 * 144), dtype=np.uint32)
         _lib.check(_lib.lib.bls381_debug_cyc_chain(ctx.handle, a.ctypes.data_as(_lib.u32p), n, out.ctypes.data_as(_lib.u32p)))
