@@ -140,7 +140,7 @@ def bench_witness(np, torch, _lib, H, B, ctx, dev):
         raise SystemExit("witness trace (host form) differs from the CPU replay of the circuit")
     res["host_256"] = {"proofs": n, "ms": dt * 1e3, "proofs_per_s": n / dt, "rows_compared_with_cpu_replay": 2 * rows}
     del trace
-    # the trace left in HBM: 16,384 proofs in one pass
+    # the trace left in HBM: 16,384 proofs in one call (the library takes them in passes of 8,192)
     n = 16384
     free = torch.cuda.mem_get_info()[0]
     while n > 1024 and n * rows * 48 > 0.8 * free:

@@ -1576,6 +1576,7 @@ extern "C" int bls381_debug_witness_cache_plan(int lanes_per_proof, int cache_ro
     if (cache_rows < 0 || cache_rows > (int)WCACHE_MAX_ROWS) return fail(BLS381_ERR_INVALID, "cache rows out of range");
     const WitnessProgram& P = witness_program();
     out[0] = out[1] = out[2] = out[3] = 0;
+    std::vector<uint8_t> not_stored(P.n_shadow[0] + P.n_shadow[1], 0);  // shadow rows kept out of global memory (both phases)
     for (int ph = 0; ph < 2; ph++) {
         size_t reads = 0, hits = 0;
         const std::vector<WitnessOp> ops = plan_row_cache(P, ph, lanes_per_proof, cache_rows, &reads, &hits);
@@ -1603,12 +1604,13 @@ extern "C" int bls381_debug_witness_cache_plan(int lanes_per_proof, int cache_ro
                 iteration++;
                 bool waits = false;
                 for (uint32_t j = i; j < e; j++) {
-                    const uint32_t kind = ops[j].dst >> 28;
+                    const uint32_t kind = (ops[j].dst >> 28) & WKIND_MASK;
                     const uint32_t refs[2] = {ops[j].a, ops[j].b};
                     const size_t row = ops[j].dst & WROW_MASK;
                     if (slot_of_row(row) == OUTSIDE || made_in[slot_of_row(row)] != NOT_MADE) out[2]++;
                     else { made_in[slot_of_row(row)] = l; made_iter[slot_of_row(row)] = iteration; }
                     if (ops[j].dst & WDRAIN_FLAG) waits = true;
+                    if (ops[j].dst & WNOSTORE_FLAG) { if (row < P.n_rows) out[2]++; else not_stored[row - P.n_rows] = 1; }
                     for (int k = 0; k < (kind == WK_NEG || kind == WK_INV ? 1 : 2); k++) {
                         const size_t src = refs[k] & WROW_MASK;
                         if ((refs[k] >> 30) == 0 && slot_of_row(src) != OUTSIDE && (made_in[slot_of_row(src)] == NOT_MADE || made_in[slot_of_row(src)] >= l))
@@ -1619,6 +1621,7 @@ extern "C" int bls381_debug_witness_cache_plan(int lanes_per_proof, int cache_ro
                         if (!(refs[k] & WCACHE_FLAG)) {
                             // a row from global memory: stored before an earlier wait of the wave, or this operation waits
                             waits = true;
+                            if (src >= P.n_rows && not_stored[src - P.n_rows]) out[2]++;  // the row is not in global memory
                             if (P.rounds && slot_of_row(src) != OUTSIDE && !(made_iter[slot_of_row(src)] < last_wait) && !(ops[j].dst & WDRAIN_FLAG)) out[2]++;
                             continue;
                         }
@@ -1641,7 +1644,7 @@ extern "C" int bls381_debug_witness_cache_plan(int lanes_per_proof, int cache_ro
         const uint32_t plan_bits = WCACHE_FLAG | (WCACHE_SLOT_MASK << WCACHE_SLOT_SHIFT);
         auto plain = [&](const WitnessOp& o) {
             const bool ta = (o.a >> 30) == 0, tb = (o.b >> 30) == 0;
-            return std::array<uint32_t, 3>{o.dst & ~(plan_bits | WDRAIN_FLAG), ta ? o.a & ~plan_bits : o.a, tb ? o.b & ~plan_bits : o.b};
+            return std::array<uint32_t, 3>{o.dst & ~(plan_bits | WDRAIN_FLAG | WNOSTORE_FLAG), ta ? o.a & ~plan_bits : o.a, tb ? o.b & ~plan_bits : o.b};
         };
         if (ops.size() != P.ops[ph].size()) out[2]++;
         else

@@ -346,14 +346,30 @@ WitnessProgram build_program(int group) {
         auto times_r = [](uint32_t ref) {  // a constant or an input in its form times 2^392
             return (ref >> 30) == 1 ? cst((int)(ref & WREF_MASK) + WC_TIMES_R) : inp((int)(ref & WREF_MASK) + WIN_COUNT);
         };
+        // A product of the two factors of an earlier product, in either order, is a copy of that row: a squaring
+        // Fq12Target::mul(x, x) asks for x_i * x_j and x_j * x_i separately (66 of its 144 products), and most
+        // Fq12 products of the circuit are the squarings of pow_target and of the Miller loop.
+        const uint32_t NONE = 0xffffffffu;
+        std::vector<uint32_t> copy_of(P.n_rows, NONE);
+        {
+            std::map<std::pair<uint32_t, uint32_t>, uint32_t> first;
+            const size_t copy_distance = getenv("BLS381_WIT_COPY_DISTANCE") ? (size_t)atol(getenv("BLS381_WIT_COPY_DISTANCE")) : 1u << 30;
+            for (size_t i = 0; i < P.n_rows; i++)
+                if (w.kinds[i] == WK_MUL) {
+                    const std::pair<uint32_t, uint32_t> key{std::min(w.ra[i], w.rb[i]), std::max(w.ra[i], w.rb[i])};
+                    auto it = first.find(key);
+                    if (it == first.end()) first[key] = (uint32_t)i;
+                    else if (i - it->second <= copy_distance) copy_of[i] = it->second;
+                    else it->second = (uint32_t)i;  // too far back to still be in the row cache: multiply again, and later copies take this row
+                }
+        }
         // in how many products between two rows a row is a factor: the factor used more often gets the shadow
         std::vector<uint32_t> uses(P.n_rows, 0);
         for (size_t i = 0; i < P.n_rows; i++)
-            if (w.kinds[i] == WK_MUL && is_row(w.ra[i]) && is_row(w.rb[i])) {
+            if (w.kinds[i] == WK_MUL && copy_of[i] == NONE && is_row(w.ra[i]) && is_row(w.rb[i])) {
                 uses[w.ra[i] & WREF_MASK]++;
                 if (w.rb[i] != w.ra[i]) uses[w.rb[i] & WREF_MASK]++;
             }
-        const uint32_t NONE = 0xffffffffu;
         std::vector<uint32_t> shadow_of(P.n_rows, NONE);
         uint32_t next_shadow = (uint32_t)P.n_rows;
         for (int phase = 0; phase < 2; phase++) {
@@ -361,6 +377,10 @@ WitnessProgram build_program(int group) {
             for (size_t i = phase_lo[phase]; i < phase_hi[phase]; i++) {
                 const uint32_t a = w.ra[i], b = w.rb[i];
                 if (w.kinds[i] != WK_MUL) { xrows[phase].push_back(XRow{w.kinds[i], (uint32_t)i, a, b}); continue; }
+                if (copy_of[i] != NONE) {
+                    xrows[phase].push_back(XRow{WK_ADD, (uint32_t)i, WREF_ROW | copy_of[i], cst(WC_ZERO)});
+                    continue;
+                }
                 if (a == cst(WC_ONE) || b == cst(WC_ONE)) {  // x * 1: a copy
                     xrows[phase].push_back(XRow{WK_ADD, (uint32_t)i, a == cst(WC_ONE) ? b : a, cst(WC_ZERO)});
                     continue;
@@ -520,7 +540,7 @@ static std::vector<WitnessOp> plan_in_order(const WitnessProgram& P, int phase, 
                                             size_t* reads_out, size_t* hits_out) {
     const auto& ls = P.level_start[phase];
     size_t reads = 0, hits = 0;
-    auto n_operands = [](const WitnessOp& o) { const uint32_t k = o.dst >> 28; return k == WK_NEG || k == WK_INV ? 1 : 2; };
+    auto n_operands = [](const WitnessOp& o) { const uint32_t k = (o.dst >> 28) & WKIND_MASK; return k == WK_NEG || k == WK_INV ? 1 : 2; };
     // iteration number of every operation
     std::vector<uint32_t> iter_of(ops.size());
     uint32_t it = 0;
@@ -539,6 +559,7 @@ static std::vector<WitnessOp> plan_in_order(const WitnessProgram& P, int phase, 
     for (size_t j = 0; j < ops.size(); j++) made_at[ops[j].dst & WROW_MASK] = iter_of[j];
     int64_t last_wait = -1;
     size_t drains = 0;
+    std::vector<uint8_t> read_from_memory(P.n_ext, 0);  // some read of the row goes to global memory
     {
         std::vector<size_t> cursor(P.n_ext, 0);
         auto next_use = [&](uint32_t row, uint32_t now) -> uint32_t {
@@ -561,6 +582,7 @@ static std::vector<WitnessOp> plan_in_order(const WitnessProgram& P, int phase, 
                     const int sl = slot_of[row];
                     if (sl >= 0) { *refs[k] |= WCACHE_FLAG | ((uint32_t)sl << WCACHE_SLOT_SHIFT); hits++; continue; }
                     reads_memory = true;
+                    read_from_memory[row] = 1;
                     // Without a barrier between rounds, a row comes from global memory only if the wave has waited for
                     // its memory operations since the row was stored: it waits whenever it loads from memory (its
                     // memory operations finish in the order it issued them), so a load issued in a later round than
@@ -592,6 +614,18 @@ static std::vector<WitnessOp> plan_in_order(const WitnessProgram& P, int phase, 
             j = e;
         }
     }
+    // A shadow row that every reader finds in the cache need not exist in global memory (the trace's own rows all do:
+    // they are the output).  Rows the other phase reads are read from memory there.
+    if (cache_rows > 0) {
+        for (const WitnessOp& o : P.ops[1 - phase]) {
+            if ((o.a >> 30) == 0) read_from_memory[o.a & WROW_MASK] = 1;
+            if (n_operands(o) == 2 && (o.b >> 30) == 0) read_from_memory[o.b & WROW_MASK] = 1;
+        }
+        for (WitnessOp& o : ops) {
+            const uint32_t row = o.dst & WROW_MASK;
+            if (row >= P.n_rows && !read_from_memory[row]) o.dst |= WNOSTORE_FLAG;
+        }
+    }
     if (reads_out) *reads_out = reads;
     if (hits_out) *hits_out = hits;
     if (getenv("BLS381_WIT_STATS")) fprintf(stderr, "witness phase %d plan: %zu operations wait for earlier stores before their reads\n", phase, drains);
@@ -615,7 +649,7 @@ std::vector<WitnessOp> plan_row_cache(const WitnessProgram& P, int phase, int lp
                 bool miss = false;
                 for (uint32_t j = i; j < std::min(i + (uint32_t)lpp, ls[l + 1]); j++) {
                     const WitnessOp& o = planned[j];
-                    const uint32_t k = o.dst >> 28;
+                    const uint32_t k = (o.dst >> 28) & WKIND_MASK;
                     miss |= (o.a >> 30) == 0 && !(o.a & WCACHE_FLAG);
                     miss |= !(k == WK_NEG || k == WK_INV) && (o.b >> 30) == 0 && !(o.b & WCACHE_FLAG);
                 }
@@ -631,7 +665,7 @@ std::vector<WitnessOp> plan_row_cache(const WitnessProgram& P, int phase, int lp
         // products first, then the other kinds one after the other (lanes of a group that hold different kinds run
         // one kind after the other); within a kind, the operations that read the trace first
         auto class_of = [&](const WitnessOp& o) {
-            const uint32_t k = o.dst >> 28;
+            const uint32_t k = (o.dst >> 28) & WKIND_MASK;
             const bool two = !(k == WK_NEG || k == WK_INV);
             const bool miss = ((o.a >> 30) == 0 && !(o.a & WCACHE_FLAG)) || (two && (o.b >> 30) == 0 && !(o.b & WCACHE_FLAG));
             const int rank = k == WK_MUL ? 0 : k == WK_ADD ? 1 : k == WK_SUB ? 2 : k == WK_NEG ? 3 : 4;
@@ -645,7 +679,7 @@ std::vector<WitnessOp> plan_row_cache(const WitnessProgram& P, int phase, int lp
                 for (uint32_t j = ls[l]; j < ls[l + 1]; j++)
                     if (class_of(planned[j]) == c) {
                         WitnessOp o = planned[j];
-                        o.dst &= ~(plan_bits | WDRAIN_FLAG);
+                        o.dst &= ~(plan_bits | WDRAIN_FLAG | WNOSTORE_FLAG);
                         if ((o.a >> 30) == 0) o.a &= ~plan_bits;
                         if ((o.b >> 30) == 0) o.b &= ~plan_bits;
                         order.push_back(o);
@@ -657,6 +691,24 @@ std::vector<WitnessOp> plan_row_cache(const WitnessProgram& P, int phase, int lp
         stats("reads of the trace gathered");
     }
     return planned;
+}
+
+std::vector<WitnessOp> pad_rounds(const WitnessProgram& P, int phase, const std::vector<WitnessOp>& planned, int lpp) {
+    const auto& ls = P.level_start[phase];
+    std::vector<WitnessOp> out;
+    out.reserve(planned.size() + ls.size() * (size_t)lpp / 2);
+    const WitnessOp nop{(uint32_t)WK_NOP << 28, 0, 0};
+    for (size_t l = 0; l + 1 < ls.size(); l++)
+        for (uint32_t i = ls[l]; i < ls[l + 1]; i += (uint32_t)lpp) {
+            const uint32_t e = std::min(i + (uint32_t)lpp, ls[l + 1]);
+            const bool level_ends = !P.rounds && e == ls[l + 1];
+            for (uint32_t j = i; j < i + (uint32_t)lpp; j++) {
+                WitnessOp o = j < e ? planned[j] : nop;
+                if (level_ends) o.dst |= WBARRIER_FLAG;
+                out.push_back(o);
+            }
+        }
+    return out;
 }
 
 const WitnessProgram& witness_program() {
@@ -697,9 +749,9 @@ __device__ __forceinline__ void w_load(const u32* base, u32 ref, const u32* T, c
 // Rows from `rows` on are the shadow rows (WitnessProgram::ops): `shadow` holds n_shadow of them per proof.
 // (Compiled for five waves per SIMD, 96 registers, so that LDS and not the register file decides how many workgroups a
 // CU holds.)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void witness_kernel(const WitnessOp* ops, const u32* level_start, int nlevels,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void witness_kernel(const WitnessOp* ops, int n_rounds,
                                                       u32* trace, size_t rows, u32* shadow, size_t n_shadow, const u32* consts,
-                                                      const u32* inputs, int lpp, int nproofs, int cache_rows, int level_barriers) {
+                                                      const u32* inputs, int lpp, int nproofs, int cache_rows, u32* trash) {
     extern __shared__ uint4 wcache[];
     const int proof = blockIdx.x * (blockDim.x / lpp) + threadIdx.x / lpp;
     const int sub = threadIdx.x % lpp;
@@ -707,6 +759,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     u32* T = trace + (size_t)(live ? proof : 0) * rows * 12;
     u32* S = shadow + (size_t)(live ? proof : 0) * n_shadow * 12;
     auto row_at = [&](u32 idx) { return idx < rows ? T + (size_t)idx * 12 : S + (size_t)(idx - (u32)rows) * 12; };
+    // where the lanes without a row in a round put their three stores: one 128-byte line per wave (the same 48 bytes
+    // from every such lane, round after round: the line stays in the L2 cache)
+    u32* const my_trash = trash + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32;
     const u32* in = inputs + (size_t)(live ? proof : 0) * WIN_TOTAL * 12;
     const u32 P[12] = BLS381_P_LIMBS;
     uint4* cdata = wcache + (size_t)(threadIdx.x / lpp) * cache_rows * 3;  // this proof's entries: 3 uint4 each
@@ -730,26 +785,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
         x[8] = c.x; x[9] = c.y; x[10] = c.z; x[11] = c.w;
     };
-    // A lane's operation is fetched one round ahead, before the round's results are stored: the wave's memory
-    // operations finish in order, so a fetch issued behind the stores would wait for them as well.
-    WitnessOp nxt = ops[0];
-    if (level_start[0] + sub < level_start[1]) nxt = ops[level_start[0] + sub];
-    for (int l = 0; l < nlevels; l++) {
-        const u32 lo = level_start[l], hi = level_start[l + 1];
-        const u32 next_hi = level_start[l + 2 <= nlevels ? l + 2 : l + 1];
-        for (u32 base = lo; base < hi; base += lpp) {  // one round: the same trip count for every lane
-            const u32 i = base + sub;
-            const bool has = live && i < hi;
+    // The operations come in rounds of lpp (pad_rounds); a lane's operation is fetched one round ahead, before the
+    // round's results are stored.  A wave's memory operations finish in the order it issued them and one counter
+    // covers loads and stores, so whatever waits for a load also waits for every store issued before it, and a
+    // store takes microseconds when the memory system is busy.  Hence: nothing is loaded per round but the
+    // operations (no table of level boundaries), and every lane stores in every round (lanes without a row to a
+    // place of their own): the compiler then knows that exactly the round's three stores follow the fetch and waits
+    // for the fetch alone.  (With the stores under a condition it waits for everything, 1.8 us per round.)
+    WitnessOp nxt = ops[sub];
+    {   // (three stores behind the first fetch as behind every other: the loop is entered in the state it repeats in)
+        uint4* d = reinterpret_cast<uint4*>(my_trash);
+        d[0] = d[1] = d[2] = make_uint4(0, 0, 0, 0);
+    }
+    for (int t = 0; t < n_rounds; t++) {
+        {
             const WitnessOp op = nxt;
-            {
-                const bool same = base + lpp < hi;  // the next round is in this level, else the first of the next level
-                const u32 j = (same ? base + lpp : hi) + sub;
-                if (j < (same ? hi : next_hi)) nxt = ops[j];
-            }
-            const u32 kind = op.dst >> 28, row = op.dst & WROW_MASK;
+            if (t + 1 < n_rounds) nxt = ops[(size_t)(t + 1) * lpp + sub];
+            const bool has = live && ((op.dst >> 28) & WKIND_MASK) != WK_NOP;
+            const u32 kind = (op.dst >> 28) & WKIND_MASK, row = op.dst & WROW_MASK;
             // (rounds without barriers: a read the plan could not place behind an earlier wait of this wave)
             if (__any(has && (op.dst & WDRAIN_FLAG))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            u32 a[12], b[12], r[12];
+            u32 a[12], b[12], r[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             if (has) {
             load(op.a, a);
             if (kind == WK_INV) {
@@ -797,10 +853,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 #pragma unroll
                 for (int k = 1; k < 12; k++) r[k] = subb_co(P[k] & m, a[k], c);
             }
-            uint4* d = reinterpret_cast<uint4*>(row_at(row));
-            d[0] = make_uint4(r[0], r[1], r[2], r[3]);
-            d[1] = make_uint4(r[4], r[5], r[6], r[7]);
-            d[2] = make_uint4(r[8], r[9], r[10], r[11]);
+            }
+            {
+                uint4* d = reinterpret_cast<uint4*>(has && !(op.dst & WNOSTORE_FLAG) ? row_at(row) : my_trash);
+                d[0] = make_uint4(r[0], r[1], r[2], r[3]);
+                d[1] = make_uint4(r[4], r[5], r[6], r[7]);
+                d[2] = make_uint4(r[8], r[9], r[10], r[11]);
             }
             // (the compiler must not move this store above the reads of this iteration, nor the next iteration's
             // reads above it: other lanes of the wave read what this lane replaces)
@@ -814,8 +872,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             }
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            // a dependency level ends (programs arranged in levels; every operation of the round says so)
+            if (op.dst & WBARRIER_FLAG) __syncthreads();
         }
-        if (level_barriers) __syncthreads();  // (uniform)
     }
 }
 
@@ -860,7 +919,7 @@ __global__ void witness_aux_kernel(const WitnessOp* ops, int nops, const u32* mu
     if (t >= (long)nproofs * nops) return;
     const int proof = (int)(t / nops);
     const WitnessOp op = ops[t % nops];
-    const u32 kind = op.dst >> 28, row = op.dst & WROW_MASK;
+    const u32 kind = (op.dst >> 28) & WKIND_MASK, row = op.dst & WROW_MASK;
     const u32* T = trace + (size_t)proof * rows * 12;
     const u32* in = inputs + (size_t)proof * WIN_TOTAL * 12;
     const u32 P[12] = BLS381_P_LIMBS;
@@ -962,9 +1021,7 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         release();  // an earlier upload that failed half-way leaves nothing behind
         for (int ph = 0; ph < 2; ph++) {
             WCHK(hipMalloc((void**)&d_ops_[ph], P.circuit_ops[ph].size() * sizeof(WitnessOp)));
-            WCHK(hipMalloc((void**)&d_levels_[ph], P.level_start[ph].size() * 4));
             WCHK(hipMemcpy(d_ops_[ph], P.circuit_ops[ph].data(), P.circuit_ops[ph].size() * sizeof(WitnessOp), hipMemcpyHostToDevice));
-            WCHK(hipMemcpy(d_levels_[ph], P.level_start[ph].data(), P.level_start[ph].size() * 4, hipMemcpyHostToDevice));
         }
         std::vector<uint32_t> wc;
         fill_wconsts(wc);
@@ -977,16 +1034,18 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         uploaded_ = true;
         prog_group_ = P.group * 2 + (P.rounds ? 1 : 0);
     }
-    // Sixteen lanes per proof, four proofs per one-wave workgroup: dependency levels are about 35 rows wide
-    // (a third of them at most 16), so wider groups mostly idle at their barriers, and the kernel hides its load
-    // latency only by the number of proofs in flight (measured, proofs/s: 256 lanes per proof x 512 proofs per
-    // pass 29 k; 64 lanes x 16,384 104 k; 32 lanes 145 k; 16 lanes 167 k; 8 lanes 162 k; with the Barrett
-    // product in place of two Montgomery products 190 k at 16 lanes).  The level assignment of build_program fills
-    // those 16 lanes: groups of 16 rows that hold a product 8,092 -> 5,159 of at least 4,416, the two kernels of
-    // 16,384 proofs 70 -> 61 ms.
+    // Sixteen lanes per proof, four proofs per one-wave workgroup.  History of the geometry (proofs/s, device form): in
+    // dependency levels about 35 rows wide, wider groups mostly idled at their barriers and the kernel hid its latency
+    // only by the number of proofs in flight: 256 lanes per proof x 512 proofs per pass 29 k; 64 lanes x 16,384 104 k;
+    // 32 lanes 145 k; 16 lanes 167 k; 8 lanes 162 k; a Barrett product in place of two Montgomery products 190 k; an LDS
+    // row cache of 48-53 rows per proof 242 k; rows held back to fill groups of 16 lanes 268 k.  In rounds without
+    // barriers (the default now), with one product instead of the Barrett product, the kernel moves 9-10 MB per proof
+    // through a memory system that 8,192-16,384 interleaved streams of 48-byte rows hold to about 3.5 TB/s, and what
+    // pays is fewer bytes: fewer proofs in flight with more cache rows each (8,192 x 104 rows: eight workgroups of
+    // 20 KB on a CU; 330-347 k against 314-340 k at 16,384 x 48, by box).
     // The staging buffer of the host-pointer form (6.8 MB per proof) keeps that form to 1,024 per pass;
     // its copy back to the host is what bounds it anyway.
-    size_t CH = on_device ? 16384 : 1024;
+    size_t CH = on_device ? (P.rounds ? 8192 : 16384) : 1024;
     int block = 64, lpp = 16;
     // tuning overrides; out-of-range values are errors (a stride of 0 would never advance the loop below)
     if (const char* e = getenv("BLS381_WIT_CH")) {
@@ -996,13 +1055,11 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
     }
     if (const char* e = getenv("BLS381_WIT_BLOCK")) block = atoi(e);
     if (const char* e = getenv("BLS381_WIT_LPP")) lpp = atoi(e);
-    // rows per proof kept in LDS, see witness_kernel and plan_row_cache (measured, proofs/s at 16 lanes per proof and
-    // 16,384 proofs in flight: none 190 k, 16 rows 218 k, 32 rows 234 k, 48 rows 242 k, 64 rows 205 k: sixteen
-    // one-wave workgroups of four proofs per CU hold 144 KiB of LDS at 48 rows; more costs occupancy).  With the
-    // level assignment and the kernel at 96 registers: 48 rows 260-265 k, 52 rows 263-274 k, 53 rows 274-275 k: 53
-    // rows are the most that leave a CU its sixteen workgroups (16 x 4 x 53 x 48 bytes = 159 of 160 KiB), the
-    // 4,096 workgroups of a pass of 16,384 proofs then are all resident at once.
-    int cache_rows = 53;
+    // rows per proof kept in LDS, see witness_kernel and plan_row_cache.  In dependency levels (measured at 16,384
+    // proofs in flight): none 190 k, 16 rows 218 k, 32 rows 234 k, 48 rows 242 k, 64 rows 205 k (sixteen one-wave
+    // workgroups of four proofs per CU hold 144 KiB of LDS at 48 rows; more costs occupancy); 53 rows are the most that
+    // leave a CU its sixteen workgroups.  In rounds: 104 rows with 8,192 proofs in flight (eight workgroups per CU).
+    int cache_rows = P.rounds ? 104 : 53;
     if (const char* e = getenv("BLS381_WIT_CACHE")) cache_rows = atoi(e);
     if (block < 1 || block > 256 || block % 64) { err = "BLS381_WIT_BLOCK must be 64, 128, 192 or 256"; return -1; }
     if (lpp < 1 || lpp > 64 || 64 % lpp) { err = "BLS381_WIT_LPP must divide 64"; return -1; }
@@ -1011,10 +1068,12 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
     if (cache_bytes > 64 * 1024) { err = "BLS381_WIT_CACHE: more than 64 KiB of LDS per workgroup"; return -1; }
     if (plan_lpp_ != lpp || plan_rows_ != cache_rows) {
         for (int ph = 0; ph < 2; ph++) {
-            const std::vector<WitnessOp> planned = plan_row_cache(P, ph, lpp, cache_rows);
-            if (!d_plan_[ph]) WCHK(hipMalloc((void**)&d_plan_[ph], planned.size() * sizeof(WitnessOp)));
+            const std::vector<WitnessOp> planned = pad_rounds(P, ph, plan_row_cache(P, ph, lpp, cache_rows), lpp);
             WCHK(hipStreamSynchronize(stream));  // an earlier pass may still read the plan being replaced
+            if (d_plan_[ph]) { WCHK(hipFree(d_plan_[ph])); d_plan_[ph] = nullptr; }  // (its size depends on lpp)
+            WCHK(hipMalloc((void**)&d_plan_[ph], planned.size() * sizeof(WitnessOp)));
             WCHK(hipMemcpy(d_plan_[ph], planned.data(), planned.size() * sizeof(WitnessOp), hipMemcpyHostToDevice));
+            n_rounds_[ph] = planned.size() / (size_t)lpp;
         }
         plan_lpp_ = lpp;
         plan_rows_ = cache_rows;
@@ -1028,6 +1087,8 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         WCHK(ensure(d_inputs_, inputs_bytes_, (size_t)m * WIN_TOTAL * 48));
         const size_t n_shadow = P.n_shadow[0] + P.n_shadow[1];
         WCHK(ensure(d_shadow_, shadow_bytes_, (size_t)m * n_shadow * 48 + 48));
+        const unsigned grid = (unsigned)((m + per_block - 1) / per_block);
+        WCHK(ensure(d_trash_, trash_bytes_, (size_t)grid * (block / 64) * 128));  // one line per wave, see witness_kernel
         WCHK(ensure(d_x_, x_bytes_, (size_t)m * 576 * 2));
         WCHK(ensure(d_g_, g_bytes_, (size_t)m * 288));
         u32* d_g1 = (u32*)d_g_;
@@ -1037,8 +1098,8 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         WCHK(hipMemcpyAsync(d_g2, g2 + off * 24, (size_t)m * 192, in_kind, stream));
         hipLaunchKernelGGL(witness_inputs_kernel, dim3((m * WIN_TOTAL + 63) / 64), dim3(64), 0, stream, d_g1, d_g2, (const u32*)d_consts_, (u32*)d_inputs_, m);
         WCHK(hipGetLastError());
-        hipLaunchKernelGGL(witness_kernel, dim3((m + per_block - 1) / per_block), dim3(block), cache_bytes, stream, d_plan_[0], d_levels_[0],
-                           (int)P.level_start[0].size() - 1, d_trace_m, P.n_rows, (u32*)d_shadow_, n_shadow, d_consts_, (const u32*)d_inputs_, lpp, m, cache_rows, P.rounds ? 0 : 1);
+        hipLaunchKernelGGL(witness_kernel, dim3(grid), dim3(block), cache_bytes, stream, d_plan_[0], (int)n_rounds_[0],
+                           d_trace_m, P.n_rows, (u32*)d_shadow_, n_shadow, d_consts_, (const u32*)d_inputs_, lpp, m, cache_rows, (u32*)d_trash_);
         WCHK(hipGetLastError());
         u32* d_x = (u32*)d_x_;
         u32* d_inv = d_x + (size_t)m * 144;
@@ -1050,8 +1111,8 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
         hipLaunchKernelGGL(witness_scatter_kernel, dim3((m * 12 + 63) / 64), dim3(64), 0, stream, d_trace_m, P.n_rows,
                            P.gen_start, d_inv, m);
         WCHK(hipGetLastError());
-        hipLaunchKernelGGL(witness_kernel, dim3((m + per_block - 1) / per_block), dim3(block), cache_bytes, stream, d_plan_[1], d_levels_[1],
-                           (int)P.level_start[1].size() - 1, d_trace_m, P.n_rows, (u32*)d_shadow_, n_shadow, d_consts_, (const u32*)d_inputs_, lpp, m, cache_rows, P.rounds ? 0 : 1);
+        hipLaunchKernelGGL(witness_kernel, dim3(grid), dim3(block), cache_bytes, stream, d_plan_[1], (int)n_rounds_[1],
+                           d_trace_m, P.n_rows, (u32*)d_shadow_, n_shadow, d_consts_, (const u32*)d_inputs_, lpp, m, cache_rows, (u32*)d_trash_);
         WCHK(hipGetLastError());
         if (aux && (aux->mul_quot || aux->carry || aux->inv_quot)) {
             const size_t n_mul = P.counts[WK_MUL];
@@ -1092,14 +1153,14 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
 
 void WitnessDevice::release() {
     for (int ph = 0; ph < 2; ph++) {
-        for (void* p : {(void*)d_ops_[ph], (void*)d_plan_[ph], (void*)d_levels_[ph]}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)d_ops_[ph], (void*)d_plan_[ph]}) if (p) (void)hipFree(p);
         d_ops_[ph] = d_plan_[ph] = nullptr;
-        d_levels_[ph] = nullptr;
+        n_rounds_[ph] = 0;
     }
     plan_lpp_ = plan_rows_ = -1;
-    for (void* p : {(void*)d_consts_, (void*)d_inv_refs_, (void*)d_mul_index_, d_trace_, d_inputs_, d_x_, d_g_, d_aux_, d_shadow_}) if (p) (void)hipFree(p);
-    d_consts_ = nullptr; d_inv_refs_ = nullptr; d_mul_index_ = nullptr; d_trace_ = d_inputs_ = d_x_ = d_g_ = d_aux_ = d_shadow_ = nullptr;
-    trace_bytes_ = inputs_bytes_ = x_bytes_ = g_bytes_ = aux_bytes_ = shadow_bytes_ = 0;
+    for (void* p : {(void*)d_consts_, (void*)d_inv_refs_, (void*)d_mul_index_, d_trace_, d_inputs_, d_x_, d_g_, d_aux_, d_shadow_, d_trash_}) if (p) (void)hipFree(p);
+    d_consts_ = nullptr; d_inv_refs_ = nullptr; d_mul_index_ = nullptr; d_trace_ = d_inputs_ = d_x_ = d_g_ = d_aux_ = d_shadow_ = d_trash_ = nullptr;
+    trace_bytes_ = inputs_bytes_ = x_bytes_ = g_bytes_ = aux_bytes_ = shadow_bytes_ = trash_bytes_ = 0;
     uploaded_ = false;
 }
 

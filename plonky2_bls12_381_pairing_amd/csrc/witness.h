@@ -20,7 +20,8 @@
 
 namespace bls381 {
 
-enum WitnessKind : uint8_t { WK_ADD = 0, WK_SUB = 1, WK_MUL = 2, WK_NEG = 3, WK_INV = 4, WK_GEN = 5 };
+enum WitnessKind : uint8_t { WK_ADD = 0, WK_SUB = 1, WK_MUL = 2, WK_NEG = 3, WK_INV = 4, WK_GEN = 5,
+                             WK_NOP = 7 };  // (only in the padded operation list the kernel walks: a lane without a row in a round)
 
 // operand reference: bits 30..31 = space (0 trace row, 1 constant, 2 circuit input), bits 0..17 = index.
 // Row indices from n_rows on name rows the kernel keeps beside the trace, in a buffer of its own (the products' left
@@ -30,7 +31,10 @@ enum WitnessKind : uint8_t { WK_ADD = 0, WK_SUB = 1, WK_MUL = 2, WK_NEG = 3, WK_
 // row an operation produces: bit 25 = the result is kept in the cache entry of bits 18..24 as well.
 enum { WREF_ROW = 0u << 30, WREF_CONST = 1u << 30, WREF_INPUT = 2u << 30, WREF_MASK = (1u << 30) - 1 };
 enum : uint32_t { WROW_MASK = (1u << 18) - 1, WCACHE_SLOT_SHIFT = 18, WCACHE_SLOT_MASK = 0x7f, WCACHE_FLAG = 1u << 25, WCACHE_MAX_ROWS = 128,
-                  WDRAIN_FLAG = 1u << 26 };  // in WitnessOp::dst: finish every earlier store before this operation's reads (see WitnessProgram::rounds)
+                  WDRAIN_FLAG = 1u << 26,    // in WitnessOp::dst: finish every earlier store before this operation's reads (see WitnessProgram::rounds)
+                  WBARRIER_FLAG = 1u << 27,  // in WitnessOp::dst, on every operation of a round: a dependency level ends with this round
+                  WNOSTORE_FLAG = 1u << 31,  // in WitnessOp::dst: a shadow row that every reader finds in the LDS row cache stays out of global memory
+                  WKIND_MASK = 7 };          // the kind is (dst >> 28) & WKIND_MASK
 
 struct WitnessOp {
     uint32_t dst;   // row index (bits 0..17) | cache fields | kind << 28
@@ -68,7 +72,8 @@ struct WitnessProgram {
     // row = 2^784 * (a trace row) / 2^392, made once by a product operation of its own and used by every product that
     // has the row as a factor (an Fq12Target::mul makes 12 of them for its 144 + 10 products).  Shadow rows have the
     // indices n_rows .. n_rows + n_shadow[0] + n_shadow[1] (phase 0's first) and live in a buffer beside the trace.
-    // A product by the constant one is a copy here (an addition of zero).
+    // A product by the constant one is a copy here (an addition of zero), and so is a product of the two factors of an
+    // earlier product (x_j * x_i after x_i * x_j in a squaring).
     std::vector<WitnessOp> ops[2];        // phase 0: rows before the generator output, phase 1: rows after
     size_t n_shadow[2] = {0, 0};
     size_t n_ext = 0;                     // n_rows + the shadow rows
@@ -90,6 +95,9 @@ const WitnessProgram& witness_program();
 // entries per proof (0: every read from the trace); optionally the number of row reads and how many the cache serves.
 std::vector<WitnessOp> plan_row_cache(const WitnessProgram& P, int phase, int lpp, int cache_rows, size_t* reads_out = nullptr,
                                       size_t* hits_out = nullptr);
+// The planned operations as the kernel walks them: rounds of exactly `lpp` entries (WK_NOP where a round has fewer
+// operations), WBARRIER_FLAG on the last round of every dependency level when the program is arranged in levels.
+std::vector<WitnessOp> pad_rounds(const WitnessProgram& P, int phase, const std::vector<WitnessOp>& planned, int lpp);
 
 struct bls381_ctx_fwd;
 
@@ -110,7 +118,8 @@ class WitnessDevice {
     WitnessOp* d_ops_[2] = {nullptr, nullptr};   // as built (the auxiliary-value kernel reads these)
     WitnessOp* d_plan_[2] = {nullptr, nullptr};  // with the row-cache plan for (plan_lpp_, plan_rows_)
     int plan_lpp_ = -1, plan_rows_ = -1;
-    uint32_t* d_levels_[2] = {nullptr, nullptr};
+    size_t n_rounds_[2] = {0, 0};
+    void* d_trash_ = nullptr;  size_t trash_bytes_ = 0;
     uint32_t* d_consts_ = nullptr;
     uint32_t* d_inv_refs_ = nullptr;
     void* d_trace_ = nullptr;  size_t trace_bytes_ = 0;
