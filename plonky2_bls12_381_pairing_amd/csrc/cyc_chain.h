@@ -31,9 +31,11 @@
 
 namespace bls381 {
 
-// Twelve waves per workgroup: four independent trios of 64 elements each.  (Workgroups of one trio leave a CU's fourth
-// SIMD idle: 65,536 elements then take 1.9 ms instead of 1.2.)
-enum { CHAIN_TRIOS = 4, CHAIN_THREADS = 192 * CHAIN_TRIOS, CHAIN_ELEMS = 64 * CHAIN_TRIOS, CHAIN_SNAPSHOTS = 6, CHAIN_ROUNDS = 63 };
+// A workgroup is TRIOS independent trios of 64 elements each.  Four trios (twelve waves) for large batches: workgroups
+// of one trio leave a CU's fourth SIMD idle (65,536 elements then take 1.9 ms instead of 1.2).  One trio for batches
+// that do not give every CU a four-trio workgroup: 16,384 elements are 64 workgroups of four trios on 64 of the 256
+// CUs (1.1 ms) or 256 of one trio, a wave on three SIMDs of every CU (0.46 ms).
+enum { CHAIN_SNAPSHOTS = 6, CHAIN_ROUNDS = 63, CHAIN_TRIOS_LARGE = 4, CHAIN_ONE_TRIO_UP_TO = 40960 };
 // bit k set: the value after k squarings is kept (the set bits of |x|)
 #define BLS381_CHAIN_KEEP 0xd201000000010000ull
 
@@ -57,7 +59,8 @@ typedef u32 chain_v16 __attribute__((ext_vector_type(16)));  // one Fp value: 14
     "+{v[0:15]}"(x0), "+{v[16:31]}"(x1), "+{v[32:47]}"(y0), "+{v[48:63]}"(y1), "+{v[64:79]}"(T0), "+{v[80:95]}"(T1), \
         "+{v[96:111]}"(XY0), "+{v[112:127]}"(XY1)
 
-__global__ __launch_bounds__(CHAIN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void cyc_chain_kernel(ChainArgs A) {
+template <int CHAIN_TRIOS>
+__global__ __launch_bounds__(192 * CHAIN_TRIOS) __attribute__((amdgpu_waves_per_eu(3, 3))) void cyc_chain_kernel(ChainArgs A) {
     // what waves 1 and 2 hand each other: [wave - 1][value 0..3][16-byte piece 0..3][lane]
     __shared__ uint4 xbuf_all[CHAIN_TRIOS * 2 * 4 * 4 * 64];
     const int lane = threadIdx.x & 63;
