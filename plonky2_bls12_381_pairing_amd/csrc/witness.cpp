@@ -8,6 +8,7 @@
 #include <memory>
 #include <mutex>
 #include <queue>
+#include <thread>
 
 #include "bls381_constants.h"
 #include "fp_dev.h"
@@ -1009,6 +1010,45 @@ static hipError_t ensure(void*& p, size_t& have, size_t need) {
     return e;
 }
 
+// Device memory to the caller's pageable memory through two pinned buffers: the DMA engine fills one (57 GB/s on
+// MI355X hosts measured here, against 17.6 GB/s for a copy straight into pageable memory, which the runtime stages
+// itself in small pieces) while host threads copy the other out (31 GB/s per thread; three threads keep up with the
+// DMA and take the first-touch page faults of a fresh destination in parallel).  Everything enqueued on `stream`
+// before the call is finished when it returns.
+int WitnessDevice::copy_out_staged(hipStream_t stream, void* dst_host, const void* src_dev, size_t bytes, std::string& err) {
+    const size_t STAGE = (size_t)64 << 20;
+    if (bytes < STAGE / 4) {  // small: not worth the pipeline
+        WCHK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, stream));
+        WCHK(hipStreamSynchronize(stream));
+        return 0;
+    }
+    for (int k = 0; k < 2; k++) {
+        if (!h_stage_[k]) WCHK(hipHostMalloc(&h_stage_[k], STAGE, hipHostMallocDefault));
+        if (!stage_ev_[k]) WCHK(hipEventCreateWithFlags(&stage_ev_[k], hipEventDisableTiming));
+    }
+    const size_t nchunks = (bytes + STAGE - 1) / STAGE;
+    auto len = [&](size_t i) { return std::min(STAGE, bytes - i * STAGE); };
+    auto issue = [&](size_t i) -> hipError_t {
+        hipError_t e = hipMemcpyAsync(h_stage_[i & 1], (const char*)src_dev + i * STAGE, len(i), hipMemcpyDeviceToHost, stream);
+        return e != hipSuccess ? e : hipEventRecord(stage_ev_[i & 1], stream);
+    };
+    WCHK(issue(0));
+    for (size_t i = 0; i < nchunks; i++) {
+        WCHK(hipEventSynchronize(stage_ev_[i & 1]));
+        if (i + 1 < nchunks) WCHK(issue(i + 1));  // (its buffer was copied out in the iteration before)
+        char* const d = (char*)dst_host + i * STAGE;
+        const char* const h = (const char*)h_stage_[i & 1];
+        const size_t n = len(i);
+        const int T = 3;
+        std::thread helpers[T - 1];
+        for (int t = 1; t < T; t++)
+            helpers[t - 1] = std::thread([=] { std::memcpy(d + n * t / T, h + n * t / T, n * (t + 1) / T - n * t / T); });
+        std::memcpy(d, h, n / T);
+        for (int t = 1; t < T; t++) helpers[t - 1].join();
+    }
+    return 0;
+}
+
 int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint64_t* g1, const uint64_t* g2, size_t n,
                        uint32_t* trace, std::string& err, bool on_device, const WitnessAux* aux) {
     const WitnessProgram& P = witness_program();
@@ -1140,12 +1180,12 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
                 WCHK(hipGetLastError());
             }
             if (!on_device) {
-                if (d_mq) WCHK(hipMemcpyAsync(aux->mul_quot + off * n_mul * 24, d_mq, (size_t)m * n_mul * 96, hipMemcpyDeviceToHost, stream));
+                if (d_mq) { int rc2 = copy_out_staged(stream, aux->mul_quot + off * n_mul * 24, d_mq, (size_t)m * n_mul * 96, err); if (rc2) return rc2; }
                 if (d_cy) WCHK(hipMemcpyAsync(aux->carry + off * P.n_rows, d_cy, (size_t)m * P.n_rows, hipMemcpyDeviceToHost, stream));
                 if (d_iq) WCHK(hipMemcpyAsync(aux->inv_quot + off * 24, d_iq, (size_t)m * 96, hipMemcpyDeviceToHost, stream));
             }
         }
-        if (!on_device) WCHK(hipMemcpyAsync(trace + off * P.n_rows * 12, d_trace_, tbytes, hipMemcpyDeviceToHost, stream));
+        if (!on_device) { int rc2 = copy_out_staged(stream, trace + off * P.n_rows * 12, d_trace_, tbytes, err); if (rc2) return rc2; }
         WCHK(hipStreamSynchronize(stream));
     }
     return 0;
@@ -1158,6 +1198,11 @@ void WitnessDevice::release() {
         n_rounds_[ph] = 0;
     }
     plan_lpp_ = plan_rows_ = -1;
+    for (int k = 0; k < 2; k++) {
+        if (h_stage_[k]) (void)hipHostFree(h_stage_[k]);
+        if (stage_ev_[k]) (void)hipEventDestroy(stage_ev_[k]);
+        h_stage_[k] = nullptr; stage_ev_[k] = nullptr;
+    }
     for (void* p : {(void*)d_consts_, (void*)d_inv_refs_, (void*)d_mul_index_, d_trace_, d_inputs_, d_x_, d_g_, d_aux_, d_shadow_, d_trash_}) if (p) (void)hipFree(p);
     d_consts_ = nullptr; d_inv_refs_ = nullptr; d_mul_index_ = nullptr; d_trace_ = d_inputs_ = d_x_ = d_g_ = d_aux_ = d_shadow_ = d_trash_ = nullptr;
     trace_bytes_ = inputs_bytes_ = x_bytes_ = g_bytes_ = aux_bytes_ = shadow_bytes_ = trash_bytes_ = 0;

@@ -120,6 +120,10 @@ class WitnessDevice {
     int plan_lpp_ = -1, plan_rows_ = -1;
     size_t n_rounds_[2] = {0, 0};
     void* d_trash_ = nullptr;  size_t trash_bytes_ = 0;
+    // large results on their way to the caller's (pageable) memory: two pinned buffers, see copy_out_staged
+    void* h_stage_[2] = {nullptr, nullptr};
+    hipEvent_t stage_ev_[2] = {nullptr, nullptr};
+    int copy_out_staged(hipStream_t stream, void* dst_host, const void* src_dev, size_t bytes, std::string& err);
     uint32_t* d_consts_ = nullptr;
     uint32_t* d_inv_refs_ = nullptr;
     void* d_trace_ = nullptr;  size_t trace_bytes_ = 0;
