@@ -166,6 +166,16 @@ def bench_witness(np, torch, _lib, H, B, ctx, dev):
     if not bool((sums == sums[0]).all()):
         raise SystemExit("witness trace checksums differ between identical proofs")
     rate = n / best
+    # memory traffic per proof by the PMC counters, recorded with tools/gpu_witness_traffic.sh (not measured in this run)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r3_witness_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath))["round3_rounds_schedule"]["hbm_bytes_per_proof"]
+        except Exception:
+            traffic = None
+    res["hbm_bytes_per_proof"] = traffic
+    res["hbm_bytes_source"] = "profiles/r3_witness_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes recorded earlier"
     res["device_%d" % n] = {"proofs": n, "ms": best * 1e3, "proofs_per_s": rate,
                             "mac_roofline_frac": rate * W_WITNESS / PEAK_MAC, "hbm_roofline_frac": rate * WITNESS_BYTES / PEAK_HBM,
                             "trace_GB_per_s_written": rate * rows * 48 / 1e9, "rows_compared_with_cpu_replay": 2 * rows,

@@ -725,14 +725,13 @@ const WitnessProgram& witness_program() {
 }
 
 // ================================================================= device
-__device__ __forceinline__ void w_load(const u32* base, u32 ref, const u32* T, const u32* consts, const u32* inputs,
-                                       u32* x) {
+// a row of the circuit's own operand spaces (the auxiliary-value kernel's loads)
+__device__ __forceinline__ void w_load(u32 ref, const u32* T, const u32* consts, const u32* inputs, u32* x) {
     const u32* p;
     u32 sp = ref >> 30, idx = ref & WROW_MASK;
     if (sp == 0) p = T + (size_t)idx * 12;
     else if (sp == 1) p = consts + (size_t)idx * 12;
     else p = inputs + (size_t)idx * 12;
-    (void)base;
     const uint4* q = reinterpret_cast<const uint4*>(p);
     uint4 a = q[0], b = q[1], c = q[2];
     x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
@@ -925,8 +924,8 @@ __global__ void witness_aux_kernel(const WitnessOp* ops, int nops, const u32* mu
     const u32* in = inputs + (size_t)proof * WIN_TOTAL * 12;
     const u32 P[12] = BLS381_P_LIMBS;
     u32 a[12], b[12], r[12];
-    w_load(T, op.a, T, consts, in, a);
-    w_load(T, WREF_ROW | row, T, consts, in, r);
+    w_load(op.a, T, consts, in, a);
+    w_load(WREF_ROW | row, T, consts, in, r);
     if (kind == WK_MUL || kind == WK_INV) {
         // (the output's base pointer is what may be null, not an address derived from it)
         u32* const qbase = kind == WK_MUL ? mul_quot : inv_quot;
@@ -934,7 +933,7 @@ __global__ void witness_aux_kernel(const WitnessOp* ops, int nops, const u32* mu
             if (carry) carry[(size_t)proof * rows + row] = 0;
             return;
         }
-        if (kind == WK_MUL) w_load(T, op.b, T, consts, in, b);
+        if (kind == WK_MUL) w_load(op.b, T, consts, in, b);
         else for (int k = 0; k < 12; k++) b[k] = r[k];  // a * a^-1
         u32 w[24];
         for (int k = 0; k < 24; k++) w[k] = 0;
@@ -971,12 +970,12 @@ __global__ void witness_aux_kernel(const WitnessOp* ops, int nops, const u32* mu
     }
     uint8_t flag = 0;
     if (kind == WK_ADD) {
-        w_load(T, op.b, T, consts, in, b);
+        w_load(op.b, T, consts, in, b);
         u32 c = 0, differs = 0;
         for (int k = 0; k < 12; k++) differs |= addc(a[k], b[k], c) ^ r[k];
         flag = (c || differs) ? 1 : 0;
     } else if (kind == WK_SUB) {
-        w_load(T, op.b, T, consts, in, b);
+        w_load(op.b, T, consts, in, b);
         u32 bw = 0;
         for (int k = 0; k < 12; k++) (void)subb(a[k], b[k], bw);
         flag = (uint8_t)bw;
