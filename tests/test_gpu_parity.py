@@ -301,12 +301,13 @@ def test_full_batch_65536_against_c_oracle_and_bilinearity(ctx, CO):
 def test_chained_final_exponentiation_on_ragged_batches(ctx, CO):
     """Batches above 8,192 pairs take the hard part's squaring chains through the register-resident kernel and the
     multiplications around them through six programs; below, one program does it all.  Ragged sizes just above the
-    switch (a last workgroup of the chain kernel with 1, 65 and 201 live elements): every output equals the same
+    switch (a last workgroup of the chain kernel with 1, 65 and 201 live elements) and around the size at which the
+    chain kernel goes from workgroups of 64 elements to workgroups of 256: every output equals the same
     inputs run in small batches through the single program, and a sample equals the CPU oracle."""
     base = 48
     ps, qs = H.random_pairs(base, 90210)
     g1b, g2b = H.g1_array(ps), H.g2_array(qs)
-    for n in (8192 + 1, 8192 + 65, 8192 + 2048 + 201):
+    for n in (8192 + 1, 8192 + 65, 8192 + 2048 + 201, 40960, 40960 + 1, 49999):   # (the chain kernel changes its workgroup shape above 40,960)
         idx_p = (np.arange(n) * 11 + 3) % base
         idx_q = (np.arange(n) // 5 + np.arange(n)) % base
         g1, g2 = g1b[idx_p], g2b[idx_q]
