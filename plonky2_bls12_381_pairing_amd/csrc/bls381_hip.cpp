@@ -1617,7 +1617,7 @@ extern "C" int bls381_debug_witness_cache_plan(int lanes_per_proof, int cache_ro
                             out[2]++;
                         // a row of the other phase must exist by now: phase 0 reads nothing of phase 1, shadow rows included
                         if ((refs[k] >> 30) == 0 && slot_of_row(src) == OUTSIDE && ph == 0 && src >= P.gen_start) out[2]++;
-                        if ((refs[k] >> 30) != 0) { if (refs[k] & WCACHE_FLAG) out[2]++; waits = true; continue; }
+                        if ((refs[k] >> 30) != 0) { if (refs[k] & WCACHE_FLAG) out[2]++; waits |= !wref_is_immediate(refs[k]); continue; }
                         if (!(refs[k] & WCACHE_FLAG)) {
                             // a row from global memory: stored before an earlier wait of the wave, or this operation waits
                             waits = true;

@@ -578,7 +578,7 @@ static std::vector<WitnessOp> plan_in_order(const WitnessProgram& P, int phase, 
             for (size_t q = j; q < e; q++) {
                 uint32_t* refs[2] = {&ops[q].a, &ops[q].b};
                 for (int k = 0; k < n_operands(ops[q]); k++) {
-                    if ((*refs[k] >> 30) != 0) { reads_memory = true; continue; }
+                    if ((*refs[k] >> 30) != 0) { reads_memory |= !wref_is_immediate(*refs[k]); continue; }
                     const uint32_t row = *refs[k] & WROW_MASK;
                     const int sl = slot_of[row];
                     if (sl >= 0) { *refs[k] |= WCACHE_FLAG | ((uint32_t)sl << WCACHE_SLOT_SHIFT); hits++; continue; }
@@ -709,6 +709,9 @@ std::vector<WitnessOp> pad_rounds(const WitnessProgram& P, int phase, const std:
                 out.push_back(o);
             }
         }
+    // whole blocks of WOPS_PER_BLOCK operations (the kernel fetches its operations a block at a time)
+    if (WOPS_PER_BLOCK % lpp == 0)
+        while (out.size() % WOPS_PER_BLOCK) out.push_back(nop);
     return out;
 }
 
@@ -773,7 +776,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         // wait for everything, and take the long way to LDS.
         typedef u32 v4u __attribute__((ext_vector_type(4)));
         v4u a, b, c;
-        if (sp == 0 && (ref & WCACHE_FLAG)) {
+        if (ref == (WREF_CONST | (u32)WC_ZERO)) {
+            a = b = c = v4u{0u, 0u, 0u, 0u};
+        } else if (ref == (WREF_CONST | (u32)WC_R2)) {
+            const u32 K[12] = BLS381_POW784_LIMBS;
+            a = v4u{K[0], K[1], K[2], K[3]}; b = v4u{K[4], K[5], K[6], K[7]}; c = v4u{K[8], K[9], K[10], K[11]};
+        } else if (sp == 0 && (ref & WCACHE_FLAG)) {
             const __attribute__((address_space(3))) v4u* q =
                 (const __attribute__((address_space(3))) v4u*)(cdata + (size_t)((ref >> WCACHE_SLOT_SHIFT) & WCACHE_SLOT_MASK) * 3);
             a = q[0]; b = q[1]; c = q[2];
@@ -781,26 +789,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             const u32* g = sp == 0 ? row_at(idx) : (sp == 1 ? consts : in) + (size_t)idx * 12;
             const __attribute__((address_space(1))) v4u* q = (const __attribute__((address_space(1))) v4u*)(uintptr_t)g;
             a = q[0]; b = q[1]; c = q[2];
+            // (the values are "used" inside this branch: the wait for the loads then sits here, where the loads are;
+            // placed behind the join of the branches it would be executed by every round, and a wait for a load is
+            // a wait for every store before it)
+            asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
         }
         x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
         x[8] = c.x; x[9] = c.y; x[10] = c.z; x[11] = c.w;
     };
-    // The operations come in rounds of lpp (pad_rounds); a lane's operation is fetched one round ahead, before the
-    // round's results are stored.  A wave's memory operations finish in the order it issued them and one counter
-    // covers loads and stores, so whatever waits for a load also waits for every store issued before it, and a
-    // store takes microseconds when the memory system is busy.  Hence: nothing is loaded per round but the
-    // operations (no table of level boundaries), and every lane stores in every round (lanes without a row to a
-    // place of their own): the compiler then knows that exactly the round's three stores follow the fetch and waits
-    // for the fetch alone.  (With the stores under a condition it waits for everything, 1.8 us per round.)
-    WitnessOp nxt = ops[sub];
-    {   // (three stores behind the first fetch as behind every other: the loop is entered in the state it repeats in)
-        uint4* d = reinterpret_cast<uint4*>(my_trash);
-        d[0] = d[1] = d[2] = make_uint4(0, 0, 0, 0);
-    }
-    for (int t = 0; t < n_rounds; t++) {
+    // A wave's memory operations finish in the order it issued them and one counter covers loads and stores, so
+    // whatever waits for a load also waits for every store issued before it, and a store takes microseconds when the
+    // memory system is busy.  A round that loads nothing from global memory waits for no store: the stores of many
+    // rounds are then under way while the wave computes (with a load per round for the round's operations the
+    // compiler put a wait for all but the two youngest memory operations between a round's stores: every round waited
+    // for the stores of the round before, 16,384 proofs took 49 ms where the arithmetic alone takes 31).  Hence:
+    //  - the operations come from LDS: rounds are padded to exactly lpp operations and whole blocks of 128 (pad_rounds);
+    //    a wave keeps two blocks in LDS, and once per block (128 / lpp rounds) its lanes fetch the block after next
+    //    from global memory, two operations each, which they put into LDS a block later;
+    //  - the constant zero and 2^784 are immediates (copies and shadow rows, a third of all operations, name them);
+    //  - operands come from the LDS row cache (98 % of them); a round in which some lane reads a row, a constant or an
+    //    input from global memory does wait;
+    //  - every lane stores in every round (lanes without a row write one 128-byte line per wave that stays in L2), so
+    //    the stores are straight-line code.
+    // (LDS address space in the pointer's type: through generic pointers these would be generic loads and stores, which
+    // count against the memory counter as well)
+    typedef __attribute__((address_space(3))) u32 lds_u32;
+    lds_u32* const ring = (lds_u32*)(reinterpret_cast<u32*>(wcache + (size_t)(blockDim.x / lpp) * cache_rows * 3) + (size_t)(threadIdx.x >> 6) * (WOPS_RING_BYTES / 4));
+    const u32 lane = threadIdx.x & 63u;
+    const int rounds_per_block = WOPS_PER_BLOCK / lpp, n_blocks = n_rounds / rounds_per_block;  // (lpp divides 64)
+    auto fetch = [&](int blk, WitnessOp& f0, WitnessOp& f1) {
+        const __attribute__((address_space(1))) u32* src = (const __attribute__((address_space(1))) u32*)(uintptr_t)(ops + (size_t)blk * WOPS_PER_BLOCK);
+        f0 = WitnessOp{src[lane * 3], src[lane * 3 + 1], src[lane * 3 + 2]};
+        f1 = WitnessOp{src[(lane + 64) * 3], src[(lane + 64) * 3 + 1], src[(lane + 64) * 3 + 2]};
+    };
+    auto stash = [&](int blk, const WitnessOp& f0, const WitnessOp& f1) {
+        lds_u32* half = ring + (size_t)(blk & 1) * WOPS_PER_BLOCK * 3;
+        half[lane * 3 + 0] = f0.dst; half[lane * 3 + 1] = f0.a; half[lane * 3 + 2] = f0.b;
+        half[(lane + 64) * 3 + 0] = f1.dst; half[(lane + 64) * 3 + 1] = f1.a; half[(lane + 64) * 3 + 2] = f1.b;
+    };
+    auto op_at = [&](int blk, int r) {
+        const lds_u32* q = ring + ((size_t)(blk & 1) * WOPS_PER_BLOCK + (size_t)r * lpp + sub) * 3;
+        return WitnessOp{q[0], q[1], q[2]};
+    };
+    if (n_blocks > 0) { WitnessOp f0, f1; fetch(0, f0, f1); stash(0, f0, f1); }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    WitnessOp nxt = n_blocks > 0 ? op_at(0, 0) : WitnessOp{(u32)WK_NOP << 28, 0, 0};
+    for (int blk = 0; blk < n_blocks; blk++)
+    for (int rd = 0; rd < rounds_per_block; rd++) {
         {
             const WitnessOp op = nxt;
-            if (t + 1 < n_rounds) nxt = ops[(size_t)(t + 1) * lpp + sub];
+            if (rd + 1 < rounds_per_block) nxt = op_at(blk, rd + 1);
             const bool has = live && ((op.dst >> 28) & WKIND_MASK) != WK_NOP;
             const u32 kind = (op.dst >> 28) & WKIND_MASK, row = op.dst & WROW_MASK;
             // (rounds without barriers: a read the plan could not place behind an earlier wait of this wave)
@@ -810,10 +849,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             load(op.a, a);
             if (kind == WK_INV) {
                 // the only inv_nonnative on the path inverts the constant 2 (curves/g2.rs:149-151)
-                const uint4* q = reinterpret_cast<const uint4*>(consts + (size_t)WC_TWO_INV * 12);
-                uint4 v0 = q[0], v1 = q[1], v2 = q[2];
-                r[0] = v0.x; r[1] = v0.y; r[2] = v0.z; r[3] = v0.w; r[4] = v1.x; r[5] = v1.y; r[6] = v1.z; r[7] = v1.w;
-                r[8] = v2.x; r[9] = v2.y; r[10] = v2.z; r[11] = v2.w;
+                load(WREF_CONST | (u32)WC_TWO_INV, r);
             } else if (kind == WK_MUL) {
                 // a = (the left factor) * 2^392, b canonical: one Montgomery product on 28-bit digits is the canonical
                 // product (every multiply-accumulate a single instruction; the Barrett product on 12 x 32-bit limbs
@@ -874,6 +910,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             __builtin_amdgcn_wave_barrier();
             // a dependency level ends (programs arranged in levels; every operation of the round says so)
             if (op.dst & WBARRIER_FLAG) __syncthreads();
+            if (rd + 1 == rounds_per_block && blk + 1 < n_blocks) {
+                // the next block goes into the half of the ring that the block before this one has left, the fetch of
+                // the block after it starts
+                WitnessOp f0, f1;
+                fetch(blk + 1, f0, f1);
+                stash(blk + 1, f0, f1);
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                nxt = op_at(blk + 1, 0);
+            }
         }
     }
 }
@@ -1098,12 +1144,12 @@ int WitnessDevice::run(hipStream_t stream, void* ctx, inverse_fn inv, const uint
     // proofs in flight): none 190 k, 16 rows 218 k, 32 rows 234 k, 48 rows 242 k, 64 rows 205 k (sixteen one-wave
     // workgroups of four proofs per CU hold 144 KiB of LDS at 48 rows; more costs occupancy); 53 rows are the most that
     // leave a CU its sixteen workgroups.  In rounds: 104 rows with 8,192 proofs in flight (eight workgroups per CU).
-    int cache_rows = P.rounds ? 104 : 53;
+    int cache_rows = P.rounds ? 88 : 37;
     if (const char* e = getenv("BLS381_WIT_CACHE")) cache_rows = atoi(e);
     if (block < 1 || block > 256 || block % 64) { err = "BLS381_WIT_BLOCK must be 64, 128, 192 or 256"; return -1; }
     if (lpp < 1 || lpp > 64 || 64 % lpp) { err = "BLS381_WIT_LPP must divide 64"; return -1; }
     if (cache_rows < 0 || cache_rows > (int)WCACHE_MAX_ROWS) { err = "BLS381_WIT_CACHE must be in 0..128"; return -1; }
-    const size_t cache_bytes = (size_t)(block / lpp) * cache_rows * 48;
+    const size_t cache_bytes = (size_t)(block / lpp) * cache_rows * 48 + (size_t)(block / 64) * WOPS_RING_BYTES;
     if (cache_bytes > 64 * 1024) { err = "BLS381_WIT_CACHE: more than 64 KiB of LDS per workgroup"; return -1; }
     if (plan_lpp_ != lpp || plan_rows_ != cache_rows) {
         for (int ph = 0; ph < 2; ph++) {

@@ -51,6 +51,13 @@ enum WitnessConst {
     WC_R2 = 48,          // 2^784: the left operand that turns a canonical row into row * 2^392
     WC_TOTAL = 49,
 };
+// Operands the kernel takes from its instruction stream instead of memory: the constant zero (a copy is an addition of
+// zero) and 2^784 (the left operand that makes a shadow row).  The cache plan and its replay count the waits of a wave
+// for its loads, so they have to agree with the kernel on what is a load.
+inline bool wref_is_immediate(uint32_t ref) { return ref == (WREF_CONST | (uint32_t)WC_ZERO) || ref == (WREF_CONST | (uint32_t)WC_R2); }
+// The kernel reads its operations from LDS: a wave keeps two blocks of WOPS_PER_BLOCK operations (128 / lpp rounds
+// each) there and fetches the block after next from global memory once per block, see witness_kernel.
+enum { WOPS_PER_BLOCK = 128, WOPS_RING_BYTES = 2 * WOPS_PER_BLOCK * 12 };
 // circuit inputs per proof: 0..5 canonical {px, py, qx.c0, qx.c1, qy.c0, qy.c1}, 6..11 the same times 2^392
 enum { WIN_COUNT = 6, WIN_TOTAL = 12 };
 
