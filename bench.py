@@ -171,7 +171,7 @@ def bench_witness(np, torch, _lib, H, B, ctx, dev):
     tpath = os.path.join(ROOT, "profiles", "r3_witness_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath))["round3_rounds_schedule"]["hbm_bytes_per_proof"]
+            traffic = json.load(open(tpath))["round3_final_kernel"]["hbm_bytes_per_proof"]
         except Exception:
             traffic = None
     res["hbm_bytes_per_proof"] = traffic

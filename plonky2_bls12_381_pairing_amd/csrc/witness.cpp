@@ -817,21 +817,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     lds_u32* const ring = (lds_u32*)(reinterpret_cast<u32*>(wcache + (size_t)(blockDim.x / lpp) * cache_rows * 3) + (size_t)(threadIdx.x >> 6) * (WOPS_RING_BYTES / 4));
     const u32 lane = threadIdx.x & 63u;
     const int rounds_per_block = WOPS_PER_BLOCK / lpp, n_blocks = n_rounds / rounds_per_block;  // (lpp divides 64)
-    auto fetch = [&](int blk, WitnessOp& f0, WitnessOp& f1) {
+    // a lane's share of a block: WOPS_PER_BLOCK / 64 operations
+    struct Share { WitnessOp o[WOPS_PER_BLOCK / 64]; };
+    auto fetch = [&](int blk, Share& f) {
         const __attribute__((address_space(1))) u32* src = (const __attribute__((address_space(1))) u32*)(uintptr_t)(ops + (size_t)blk * WOPS_PER_BLOCK);
-        f0 = WitnessOp{src[lane * 3], src[lane * 3 + 1], src[lane * 3 + 2]};
-        f1 = WitnessOp{src[(lane + 64) * 3], src[(lane + 64) * 3 + 1], src[(lane + 64) * 3 + 2]};
+#pragma unroll
+        for (int i = 0; i < WOPS_PER_BLOCK / 64; i++)
+            f.o[i] = WitnessOp{src[(lane + 64 * i) * 3], src[(lane + 64 * i) * 3 + 1], src[(lane + 64 * i) * 3 + 2]};
     };
-    auto stash = [&](int blk, const WitnessOp& f0, const WitnessOp& f1) {
+    auto stash = [&](int blk, const Share& f) {
         lds_u32* half = ring + (size_t)(blk & 1) * WOPS_PER_BLOCK * 3;
-        half[lane * 3 + 0] = f0.dst; half[lane * 3 + 1] = f0.a; half[lane * 3 + 2] = f0.b;
-        half[(lane + 64) * 3 + 0] = f1.dst; half[(lane + 64) * 3 + 1] = f1.a; half[(lane + 64) * 3 + 2] = f1.b;
+#pragma unroll
+        for (int i = 0; i < WOPS_PER_BLOCK / 64; i++) {
+            half[(lane + 64 * i) * 3 + 0] = f.o[i].dst; half[(lane + 64 * i) * 3 + 1] = f.o[i].a; half[(lane + 64 * i) * 3 + 2] = f.o[i].b;
+        }
     };
     auto op_at = [&](int blk, int r) {
         const lds_u32* q = ring + ((size_t)(blk & 1) * WOPS_PER_BLOCK + (size_t)r * lpp + sub) * 3;
         return WitnessOp{q[0], q[1], q[2]};
     };
-    if (n_blocks > 0) { WitnessOp f0, f1; fetch(0, f0, f1); stash(0, f0, f1); }
+    if (n_blocks > 0) { Share f; fetch(0, f); stash(0, f); }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     WitnessOp nxt = n_blocks > 0 ? op_at(0, 0) : WitnessOp{(u32)WK_NOP << 28, 0, 0};
@@ -913,9 +918,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             if (rd + 1 == rounds_per_block && blk + 1 < n_blocks) {
                 // the next block goes into the half of the ring that the block before this one has left, the fetch of
                 // the block after it starts
-                WitnessOp f0, f1;
-                fetch(blk + 1, f0, f1);
-                stash(blk + 1, f0, f1);
+                Share f;
+                fetch(blk + 1, f);
+                stash(blk + 1, f);
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 nxt = op_at(blk + 1, 0);
