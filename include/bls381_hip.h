@@ -231,7 +231,7 @@ int bls381_pairing_batch_dev_noalloc(bls381_ctx*, const uint64_t* g1_dev, const 
                                      const uint8_t* inf_flags_dev, size_t n, uint64_t* out_fq12_dev);
 
 /* Introspection used by the tests and the benchmark. */
-/* Builds and schedules the step program `which` ("miller", "millerfq", "miller2", "fe1", "fe2", "fe2s0" .. "fe2s5", "g2prep", "ell", "fq12mul",
+/* Builds and schedules the step program `which` ("miller", "millerfq", "miller2", "fe1", "fe2", "fe2s0" .. "fe2s5", "g2prep", "g1sub", "g2sub", "ell", "fq12mul",
  * "easy2", "hardgen", "inv1", "inv2", "conj", "frob0" .. "frob11", "pow:<16 hex digits per exponent word>") for groups of K lanes and copies it into
  * caller buffers: hdrs = nsteps x 2 u32, descs = nsteps x K x 12 u32.  info[8] receives
  * {K, nsteps, lds_slots, tmp_slots, n_in, n_out, multiply-accumulates executed (300 per product, 444 per two-product sum), n_lin}.  Pass NULL buffers to query sizes.
@@ -303,7 +303,8 @@ int bls381_fq6_inverse_limbs_batch(bls381_ctx*, const uint32_t* x, size_t n, uin
  * BLS381_ERR_POINT after filling everything.  A point at infinity is status 1 with a zero point:
  * pass it on through inf_flags.  check_subgroup != 0 also runs the order-r membership test that
  * deserialize_compressed performs (Validate::Yes); 0 corresponds to deserialize_compressed_unchecked
- * plus the on-curve test. */
+ * plus the on-curve test.  (The membership tests of G2 points, and of G1 points in batches of at most 8,192, run as
+ * step programs over lane groups after the decoder: 65,536 G2 points 4.5 ms decoded and tested.) */
 int bls381_g1_decompress_batch(bls381_ctx*, const uint8_t* in48, size_t n, int check_subgroup, uint64_t* g1,
                                uint8_t* status);
 int bls381_g2_decompress_batch(bls381_ctx*, const uint8_t* in96, size_t n, int check_subgroup, uint64_t* g2,

@@ -62,6 +62,8 @@ static Dag build_named(const std::string& which, int K) {
     if (which == "miller2") return build_miller_two_pairs();
     if (which == "miller2s") return build_miller_two_pairs(true);
     if (which == "ell") return build_ell();
+    if (which == "g2sub") return build_g2_subgroup();
+    if (which == "g1sub") return build_g1_subgroup();
     if (which == "fe1") return build_final_exp_part1();
     if (which == "fe2") return build_final_exp_part2(true);
     if (which.size() == 5 && which.rfind("fe2s", 0) == 0 && which[4] >= '0' && which[4] <= '5') return build_final_exp_chain_part(which[4] - '0');
@@ -176,7 +178,7 @@ struct bls381_ctx {
     bool chain_timed = false;        // the last final exponentiation went through the squaring-chain kernel
     float last_chain_ms[2] = {0, 0};  // its five chain launches together, its six programs together
     const int* n_dev_override = nullptr;  // set while a program runs over a count that lives on the device
-    DevBuf vbuf[8];  // stages of the signature check from bytes
+    DevBuf vbuf[9];  // stages of the signature check from bytes; [8]: what the G2 subgroup-test program returns
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float last_ms[4] = {0, 0, 0, 0};  // Miller kernel, fe1 + inversion, fe2 kernel, whole device call
     std::mutex mu;
@@ -1843,6 +1845,33 @@ extern "C" int bls381_fq6_inverse_limbs_batch(bls381_ctx* c, const uint32_t* x, 
 
 // ------------------------------------------------------------------ compressed points, aggregation
 static const size_t MAX_POINTS = (size_t)1 << 22;
+// The order-r test of decoded points as a step program over lane groups (build_g2_subgroup, build_g1_subgroup) instead
+// of one lane per point inside the decoder.  G2: 65,536 points take 2.3 ms this way against 5.0 ms, one point 0.3 ms
+// against 3 ms.  G1 (twice the doublings, in Fq: half of a lane group's lanes idle): only for batches small enough
+// that latency is what counts.
+// pts_dev: n affine points (Montgomery limbs, zero where the decoder rejected the encoding); status_dev: the decoder's
+// status bytes, where ST_OK becomes ST_NOT_IN_SUBGROUP for the points that fail (and the point zero, as the decoder
+// leaves every point it rejects).  Runs on the context's stream and returns with it synchronised.
+// BLS381_G2_SUBGROUP_PROGRAM=0 / BLS381_G1_SUBGROUP_PROGRAM=0 keep the tests inside the decoders.
+static bool env_on(const char* name) {
+    const char* e = getenv(name);  // (read per call: the tests run both forms in one process)
+    return !(e && atoi(e) == 0);
+}
+static bool g2_subgroup_as_program() { return env_on("BLS381_G2_SUBGROUP_PROGRAM"); }
+static bool g1_subgroup_as_program(size_t n) { return n <= (size_t)SMALL_BATCH && env_on("BLS381_G1_SUBGROUP_PROGRAM"); }
+static int subgroup_dev(bls381_ctx* c, const char* prog, int fq, u32* pts_dev, size_t n, uint8_t* status_dev) {
+    if (n == 0) return 0;
+    DevBuf& diff = c->vbuf[8];
+    HIPCHK(diff.ensure(n * 2 * fq * 48));
+    int rc = simple_dev_locked(c, prog, {{pts_dev, 2 * fq}}, n, diff.p, 2 * fq, CHUNK);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pts::subgroup_status_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, (const u32*)diff.p,
+                       2 * fq * 12, (int)n, status_dev, pts_dev, 2 * fq * 12);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int g2_subgroup_dev(bls381_ctx* c, u32* pts_dev, size_t n, uint8_t* status_dev) { return subgroup_dev(c, "g2sub", 2, pts_dev, n, status_dev); }
+static int g1_subgroup_dev(bls381_ctx* c, u32* pts_dev, size_t n, uint8_t* status_dev) { return subgroup_dev(c, "g1sub", 1, pts_dev, n, status_dev); }
 // n encodings of `bytes_per` bytes -> n affine points of `fq_out` Fq each + one status byte per point
 template <typename Launch>
 static int decompress_host(bls381_ctx* c, const uint8_t* in, size_t n, size_t bytes_per, size_t fq_out, uint64_t* out,
@@ -1854,8 +1883,7 @@ static int decompress_host(bls381_ctx* c, const uint8_t* in, size_t n, size_t by
     if ((rc = h2d(c, c->user_in, in, n * bytes_per))) return rc;
     HIPCHK(c->user_out.ensure(n * fq_out * 48));
     HIPCHK(c->zflags.ensure(n));
-    launch((const uint8_t*)c->user_in.p, (int)n, (u32*)c->user_out.p, (uint8_t*)c->zflags.p);
-    HIPCHK(hipGetLastError());
+    if ((rc = launch((const uint8_t*)c->user_in.p, (int)n, (u32*)c->user_out.p, (uint8_t*)c->zflags.p))) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, c->user_out.p, n * fq_out * 48, hipMemcpyDeviceToHost));
     std::vector<uint8_t> st(n);
@@ -1871,15 +1899,21 @@ static int decompress_host(bls381_ctx* c, const uint8_t* in, size_t n, size_t by
 extern "C" int bls381_g1_decompress_batch(bls381_ctx* c, const uint8_t* in, size_t n, int check_subgroup, uint64_t* g1,
                                           uint8_t* status) {
     CTX_GUARD(c);
+    const bool as_program = check_subgroup && g1_subgroup_as_program(n);
     return decompress_host(c, in, n, 48, 2, g1, status, [&](const uint8_t* d, int m, u32* o, uint8_t* s) {
-        hipLaunchKernelGGL(pts::g1_decompress_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, d, m, check_subgroup, o, s);
+        hipLaunchKernelGGL(pts::g1_decompress_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, d, m, as_program ? 0 : check_subgroup, o, s);
+        HIPCHK(hipGetLastError());
+        return as_program ? g1_subgroup_dev(c, o, (size_t)m, s) : 0;
     });
 }
 extern "C" int bls381_g2_decompress_batch(bls381_ctx* c, const uint8_t* in, size_t n, int check_subgroup, uint64_t* g2,
                                           uint8_t* status) {
     CTX_GUARD(c);
+    const bool as_program = check_subgroup && g2_subgroup_as_program();
     return decompress_host(c, in, n, 96, 4, g2, status, [&](const uint8_t* d, int m, u32* o, uint8_t* s) {
-        hipLaunchKernelGGL(pts::g2_decompress_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, d, m, check_subgroup, o, s);
+        hipLaunchKernelGGL(pts::g2_decompress_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, d, m, as_program ? 0 : check_subgroup, o, s);
+        HIPCHK(hipGetLastError());
+        return as_program ? g2_subgroup_dev(c, o, (size_t)m, s) : 0;
     });
 }
 template <typename Launch>
@@ -1982,8 +2016,7 @@ extern "C" int bls381_verify_batch(bls381_ctx* c, const uint8_t* pk48, const uin
     DevBuf* v = c->vbuf;
     HIPCHK(v[B_BYTES].ensure(n * 240));
     HIPCHK(v[B_G1A].ensure(n * 96));
-    HIPCHK(v[B_G2A].ensure(n * 192));
-    HIPCHK(v[B_G2B].ensure(n * 192));
+    HIPCHK(v[B_G2A].ensure(n * 384));  // message points, then signatures: one run of the subgroup-test program takes both
     HIPCHK(v[B_G1B].ensure(n * 96));
     HIPCHK(v[B_STATUS].ensure(n * 3));
     HIPCHK(v[B_FLAGS].ensure(n * 2));
@@ -2000,26 +2033,41 @@ extern "C" int bls381_verify_batch(bls381_ctx* c, const uint8_t* pk48, const uin
     // on three streams and share the GPU.
     uint8_t* bytes = (uint8_t*)v[B_BYTES].p;
     HIPCHK(hipMemcpyAsync(bytes, pk48, n * 48, hipMemcpyHostToDevice, c->copy_stream));
+    const bool test_keys = check_subgroup & BLS381_CHECK_KEYS, keys_as_program = test_keys && g1_subgroup_as_program(n);
     hipLaunchKernelGGL(pts::g1_decompress_kernel, grid, block, 0, c->copy_stream, (const uint8_t*)bytes, m,
-                       (check_subgroup & BLS381_CHECK_KEYS) ? 1 : 0, (u32*)v[B_G1A].p, st);
+                       (test_keys && !keys_as_program) ? 1 : 0, (u32*)v[B_G1A].p, st);
     HIPCHK(hipEventRecord(c->pipe_ev[0], c->copy_stream));
     HIPCHK(hipMemcpyAsync(bytes + n * 48, msg96, n * 96, hipMemcpyHostToDevice, c->aux_stream));
+    // (the G2 points' subgroup tests run as a step program after the decoders, see g2_subgroup_dev)
+    const bool as_program = g2_subgroup_as_program();
+    const bool test_msg = check_subgroup & BLS381_CHECK_MESSAGES, test_sig = check_subgroup & BLS381_CHECK_SIGNATURES;
+    u32 *g2_msg = (u32*)v[B_G2A].p, *g2_sig = g2_msg + n * 48;
     hipLaunchKernelGGL(pts::g2_decompress_kernel, grid, block, 0, c->aux_stream, (const uint8_t*)bytes + n * 48, m,
-                       (check_subgroup & BLS381_CHECK_MESSAGES) ? 1 : 0, (u32*)v[B_G2A].p, st + n);
+                       (test_msg && !as_program) ? 1 : 0, g2_msg, st + n);
     HIPCHK(hipEventRecord(c->pipe_ev[1], c->aux_stream));
     HIPCHK(hipMemcpyAsync(bytes + n * 144, sig96, n * 96, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(pts::g2_decompress_kernel, grid, block, 0, c->stream, (const uint8_t*)bytes + n * 144, m,
-                       (check_subgroup & BLS381_CHECK_SIGNATURES) ? 1 : 0, (u32*)v[B_G2B].p, st + 2 * n);
-    HIPCHK(hipStreamWaitEvent(c->stream, c->pipe_ev[0], 0));
+                       (test_sig && !as_program) ? 1 : 0, g2_sig, st + 2 * n);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamWaitEvent(c->stream, c->pipe_ev[1], 0));
+    if (as_program && (test_msg || test_sig)) {
+        int rc2 = test_msg && test_sig ? g2_subgroup_dev(c, g2_msg, 2 * n, st + n)
+                                       : g2_subgroup_dev(c, test_msg ? g2_msg : g2_sig, n, test_msg ? st + n : st + 2 * n);
+        if (rc2) return rc2;
+    }
+    HIPCHK(hipStreamWaitEvent(c->stream, c->pipe_ev[0], 0));
+    if (keys_as_program) {
+        int rc2 = g1_subgroup_dev(c, (u32*)v[B_G1A].p, n, st);
+        if (rc2) return rc2;
+    }
     hipLaunchKernelGGL(pts::fill_neg_g1_generator, grid, block, 0, c->stream, (u32*)v[B_G1B].p, m);
     uint8_t* flags = (uint8_t*)v[B_FLAGS].p;
     uint8_t* valid = flags + n;
     hipLaunchKernelGGL(pts::verify_flags_kernel, grid, block, 0, c->stream, st, st + n, st + 2 * n, m, flags, valid);
     HIPCHK(hipGetLastError());
     uint8_t* is_one = (uint8_t*)v[B_ONE].p;
-    int rc = two_pairs_dev_locked(c, (const uint64_t*)v[B_G1A].p, (const uint64_t*)v[B_G2A].p, (const uint64_t*)v[B_G1B].p,
-                                  (const uint64_t*)v[B_G2B].p, flags, n, nullptr, is_one, true);
+    int rc = two_pairs_dev_locked(c, (const uint64_t*)v[B_G1A].p, (const uint64_t*)g2_msg, (const uint64_t*)v[B_G1B].p,
+                                  (const uint64_t*)g2_sig, flags, n, nullptr, is_one, true);
     if (rc) return rc;
     hipLaunchKernelGGL(pts::verify_verdict_kernel, grid, block, 0, c->stream, is_one, valid, m, is_one + n);
     HIPCHK(hipGetLastError());
@@ -2051,13 +2099,12 @@ extern "C" int bls381_fast_aggregate_verify_batch(bls381_ctx* c, const uint8_t* 
     const size_t g = n_checks, n = n_checks * keys_per_check;
     HIPCHK(v[B_BYTES].ensure(n * 48 + g * 192));
     HIPCHK(v[B_G1A].ensure(n * 96 + g * 96));  // the keys, then their sums
-    HIPCHK(v[B_G2A].ensure(g * 192));
-    HIPCHK(v[B_G2B].ensure(g * 192));
+    HIPCHK(v[B_G2A].ensure(g * 384));  // message points, then signatures
     HIPCHK(v[B_G1B].ensure(g * 96));
     HIPCHK(v[B_STATUS].ensure(n + 4 * g));
     HIPCHK(v[B_FLAGS].ensure(2 * g));
     HIPCHK(v[B_ONE].ensure(2 * g));
-    while (c->pipe_ev.size() < 2) {
+    while (c->pipe_ev.size() < 3) {
         hipEvent_t e;
         HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->pipe_ev.push_back(e);
@@ -2068,34 +2115,55 @@ extern "C" int bls381_fast_aggregate_verify_batch(bls381_ctx* c, const uint8_t* 
     const int gi = (int)g;
     const dim3 ggrid((gi + 63) / 64), block(64);
     HIPCHK(hipMemcpyAsync(bytes + n * 48, msg96, g * 96, hipMemcpyHostToDevice, c->copy_stream));
+    const bool as_program = g2_subgroup_as_program();
+    const bool test_msg = check_subgroup & BLS381_CHECK_MESSAGES, test_sig = check_subgroup & BLS381_CHECK_SIGNATURES;
+    u32 *g2_msg = (u32*)v[B_G2A].p, *g2_sig = g2_msg + g * 48;
     hipLaunchKernelGGL(pts::g2_decompress_kernel, ggrid, block, 0, c->copy_stream, (const uint8_t*)bytes + n * 48, gi,
-                       (check_subgroup & BLS381_CHECK_MESSAGES) ? 1 : 0, (u32*)v[B_G2A].p, st_msg);
+                       (test_msg && !as_program) ? 1 : 0, g2_msg, st_msg);
     HIPCHK(hipEventRecord(c->pipe_ev[0], c->copy_stream));
     HIPCHK(hipMemcpyAsync(bytes + n * 48 + g * 96, sig96, g * 96, hipMemcpyHostToDevice, c->aux_stream));
     hipLaunchKernelGGL(pts::g2_decompress_kernel, ggrid, block, 0, c->aux_stream, (const uint8_t*)bytes + n * 48 + g * 96, gi,
-                       (check_subgroup & BLS381_CHECK_SIGNATURES) ? 1 : 0, (u32*)v[B_G2B].p, st_sig);
+                       (test_sig && !as_program) ? 1 : 0, g2_sig, st_sig);
     HIPCHK(hipEventRecord(c->pipe_ev[1], c->aux_stream));
-    HIPCHK(hipMemcpyAsync(bytes, pk48, n * 48, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(pts::g1_decompress_kernel, dim3((unsigned)((n + 63) / 64)), block, 0, c->stream, (const uint8_t*)bytes,
-                       (int)n, (check_subgroup & BLS381_CHECK_KEYS) ? 1 : 0, (u32*)v[B_G1A].p, st);
+    // Keys whose subgroup tests run inside the decoder (one lane per key: milliseconds) are decoded on the third stream,
+    // behind the signature, while this stream takes the two G2 points through the subgroup-test program; otherwise on
+    // this stream, beside the two G2 decoders.
+    const bool test_keys = check_subgroup & BLS381_CHECK_KEYS, keys_as_program = test_keys && g1_subgroup_as_program(n);
+    hipStream_t key_stream = (test_keys && !keys_as_program) ? c->aux_stream : c->stream;
+    HIPCHK(hipMemcpyAsync(bytes, pk48, n * 48, hipMemcpyHostToDevice, key_stream));
+    hipLaunchKernelGGL(pts::g1_decompress_kernel, dim3((unsigned)((n + 63) / 64)), block, 0, key_stream, (const uint8_t*)bytes,
+                       (int)n, (test_keys && !keys_as_program) ? 1 : 0, (u32*)v[B_G1A].p, st);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->pipe_ev[2], key_stream));
+    // the two G2 points on this stream once their decoders are through: the subgroup-test program where it is asked for
+    auto g2_points = [&]() -> int {
+        HIPCHK(hipStreamWaitEvent(c->stream, c->pipe_ev[0], 0));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->pipe_ev[1], 0));
+        if (!as_program || !(test_msg || test_sig)) return 0;
+        // (the statuses of message points and signatures are adjacent, as the points are)
+        return test_msg && test_sig ? g2_subgroup_dev(c, g2_msg, 2 * g, st_msg)
+                                    : g2_subgroup_dev(c, test_msg ? g2_msg : g2_sig, g, test_msg ? st_msg : st_sig);
+    };
+    int rc = 0;
+    if (key_stream != c->stream && (rc = g2_points())) return rc;  // (while the keys are tested on their stream)
+    HIPCHK(hipStreamWaitEvent(c->stream, c->pipe_ev[2], 0));
+    if (keys_as_program && (rc = g1_subgroup_dev(c, (u32*)v[B_G1A].p, n, st))) return rc;
     u32* sums = (u32*)v[B_G1A].p + n * 24;
     // (rejected keys are zero points: their sums mean nothing and the group status below overrides them)
-    int rc = aggregate_dev<gen::F>(c, (const u32*)v[B_G1A].p, nullptr, g, keys_per_check, sums, sum_inf);
+    rc = aggregate_dev<gen::F>(c, (const u32*)v[B_G1A].p, nullptr, g, keys_per_check, sums, sum_inf);
     if (rc) return rc;
     hipLaunchKernelGGL(pts::group_status_kernel, ggrid, block, 0, c->stream, (const uint8_t*)st, (const uint8_t*)sum_inf, gi,
                        (int)keys_per_check, st_sum);
     hipLaunchKernelGGL(pts::fill_neg_g1_generator, ggrid, block, 0, c->stream, (u32*)v[B_G1B].p, gi);
-    HIPCHK(hipStreamWaitEvent(c->stream, c->pipe_ev[0], 0));
-    HIPCHK(hipStreamWaitEvent(c->stream, c->pipe_ev[1], 0));
+    if (key_stream == c->stream && (rc = g2_points())) return rc;  // (the G2 decoders ran beside the keys' work)
     uint8_t* flags = (uint8_t*)v[B_FLAGS].p;
     uint8_t* valid = flags + g;
     hipLaunchKernelGGL(pts::verify_flags_kernel, ggrid, block, 0, c->stream, (const uint8_t*)st_sum, (const uint8_t*)st_msg,
                        (const uint8_t*)st_sig, gi, flags, valid);
     HIPCHK(hipGetLastError());
     uint8_t* is_one = (uint8_t*)v[B_ONE].p;
-    rc = two_pairs_dev_locked(c, (const uint64_t*)sums, (const uint64_t*)v[B_G2A].p, (const uint64_t*)v[B_G1B].p,
-                              (const uint64_t*)v[B_G2B].p, flags, g, nullptr, is_one, true);
+    rc = two_pairs_dev_locked(c, (const uint64_t*)sums, (const uint64_t*)g2_msg, (const uint64_t*)v[B_G1B].p,
+                              (const uint64_t*)g2_sig, flags, g, nullptr, is_one, true);
     if (rc) return rc;
     hipLaunchKernelGGL(pts::verify_verdict_kernel, ggrid, block, 0, c->stream, is_one, valid, gi, is_one + g);
     HIPCHK(hipGetLastError());

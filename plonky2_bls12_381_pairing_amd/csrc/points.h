@@ -245,6 +245,19 @@ __global__ __launch_bounds__(64) void g2_decompress_kernel(const uint8_t* in, in
     store_f(o + 24, good ? y.c0 : z); store_f(o + 36, good ? y.c1 : z);
     status[i] = st;
 }
+// What a subgroup-test program (build_g1_subgroup / build_g2_subgroup) returned for n decoded points: diff_words words
+// each, all zero for a point of the subgroup.  A point the decoder accepted that fails becomes ST_NOT_IN_SUBGROUP and,
+// like every rejected point, zero (pt_words words).
+__global__ __launch_bounds__(64) void subgroup_status_kernel(const u32* diff, int diff_words, int n, uint8_t* status, u32* pts,
+                                                             int pt_words) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || status[i] != ST_OK) return;
+    u32 nz = 0;
+    for (int k = 0; k < diff_words; k++) nz |= diff[(size_t)i * diff_words + k];
+    if (nz == 0) return;
+    status[i] = ST_NOT_IN_SUBGROUP;
+    for (int k = 0; k < pt_words; k++) pts[(size_t)i * pt_words + k] = 0;
+}
 // points: n x {x, y} Montgomery limbs, inf: n bytes (may be null) -> n x 48 bytes
 __global__ __launch_bounds__(64) void g1_compress_kernel(const u32* pts, const uint8_t* inf, int n, uint8_t* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -98,6 +98,10 @@ Dag build_g2_prepare();
 // (a prepared G2 point shared by the whole batch).  gin: G1 (2); gout: Fq12 (12).
 Dag build_miller_fixed_q();
 Dag build_miller_two_pairs(bool scaled = false);  // scaled: G2 doublings without the halvings, as build_miller_scaled
+// psi(Q) = [z]Q on a decoded G2 point (see tower_sym.cpp).  gin: G2 (4); gout: 4 values, all zero iff Q is in G2.
+Dag build_g2_subgroup();
+// (beta x, y) = [-z^2]P on a decoded G1 point.  gin: G1 (2); gout: 2 values, both zero iff P is in G1.
+Dag build_g1_subgroup();
 // ell(f, coeffs, p).                                         /root/reference/src/native/miller_loop.rs:185-194
 // gin: f (12) + coeff (6) + G1 (2); gout: f (12).
 Dag build_ell();

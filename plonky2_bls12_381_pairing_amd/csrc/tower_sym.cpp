@@ -622,6 +622,119 @@ Dag build_g2_prepare() {
     return d;
 }
 
+// Membership of a point of the twist in the order-r subgroup: psi(Q) = [z]Q with z = -|x| (Scott, "A note on group
+// membership tests for G1, G2 and GT on BLS pairing-friendly curves"; the test ark-bls12-381 0.4.0 runs on a decoded
+// G2 point, /root/reference/Cargo.toml:13).  R = [|x|]Q by complete projective doublings and additions (Renes,
+// Costello, Batina 2016, algorithms 7 and 9 for a = 0; the twist has odd order, so they have no exceptional inputs),
+// psi(x, y) = (conj(x) / xi^((p-1)/3), conj(y) / xi^((p-1)/2)).  psi(Q) = -R in projective coordinates, cleared of the
+// two divisions:  conj(x) Z = X xi^((p-1)/3)  and  conj(y) Z = -Y xi^((p-1)/2).
+// gin: Q affine (4); gout: the two differences (4): all zero iff Q is in the subgroup (Q itself not infinity).
+Dag build_g2_subgroup() {
+    Dag d;
+    d.n_in = 4; d.n_out = 4;
+    Tower T(d);
+    const SFq2 qx{T.in(0), T.in(1)}, qy{T.in(2), T.in(3)};
+    auto b3 = [&](const SFq2& a) {  // 3 b a with b = 4 (1 + u)  (12 a first: a sum's digits must stay within 32 bits)
+        return T.mul_xi(T.lin2({{a, 12}}));
+    };
+    struct Pt { SFq2 X, Y, Z; };
+    // (with s = 3 xi Z^2 = t2 / 4 of the paper's algorithm: the sums between a doubling's two levels of products are two
+    // deep instead of three, and every coefficient sum stays within the digits' 32 bits)
+    auto dbl = [&](const Pt& p) {
+        SFq2 t0 = T.sqr(p.Y);
+        SFq2 z8 = T.lin2({{t0, 8}});
+        SFq2 t1 = T.mul(p.Y, p.Z);
+        SFq2 zz = T.sqr(p.Z);
+        SFq2 s{T.lin({{zz.c0, 3}, {zz.c1, -3}}), T.lin({{zz.c0, 3}, {zz.c1, 3}})};
+        SFq2 xy = T.mul(p.X, p.Y);
+        SFq2 x3 = T.mul(T.lin2({{s, 4}}), z8);
+        SFq2 z3 = T.mul(t1, z8);
+        SFq2 t0m = T.lin2({{t0, 1}, {s, -12}});
+        SFq2 y3 = T.add(x3, T.mul(t0m, T.lin2({{t0, 1}, {s, 4}})));
+        SFq2 xo = T.lin2({{T.mul(t0m, xy), 2}});
+        return Pt{xo, y3, z3};
+    };
+    auto add_q = [&](const Pt& p) {  // p + (qx, qy, 1)
+        SFq2 t0 = T.mul(p.X, qx), t1 = T.mul(p.Y, qy), t2 = p.Z;
+        SFq2 t3 = T.sub(T.mul(T.add(p.X, p.Y), T.add(qx, qy)), T.add(t0, t1));
+        SFq2 t4 = T.add(T.mul(qy, p.Z), p.Y);   // (Y1 + Z1)(qy + 1) - t1 - t2
+        SFq2 y3 = T.add(T.mul(qx, p.Z), p.X);   // (X1 + Z1)(qx + 1) - t0 - t2
+        SFq2 x3 = T.lin2({{t0, 3}});
+        t2 = b3(t2);
+        SFq2 z3 = T.add(t1, t2);
+        t1 = T.sub(t1, t2);
+        y3 = b3(y3);
+        SFq2 xo = T.sub(T.mul(t3, t1), T.mul(t4, y3));
+        SFq2 yo = T.add(T.mul(t1, z3), T.mul(y3, x3));
+        SFq2 zo = T.add(T.mul(z3, t4), T.mul(x3, t3));
+        return Pt{xo, yo, zo};
+    };
+    Pt r{qx, qy, T.one2()};
+    for (int i = 62; i >= 0; i--) {
+        r = dbl(r);
+        if ((0xd201000000010000ull >> i) & 1ull) r = add_q(r);
+    }
+    const SFq2 g2{T.cst(C_FROB1_BASE + 2), T.cst(C_FROB1_BASE + 3)}, g3{T.cst(C_FROB1_BASE + 4), T.cst(C_FROB1_BASE + 5)};
+    const SFq2 e1 = T.sub(T.mul(T.conj(qx), r.Z), T.mul(r.X, g2));
+    const SFq2 e2 = T.add(T.mul(T.conj(qy), r.Z), T.mul(r.Y, g3));
+    T.out(e1.c0, 0); T.out(e1.c1, 1); T.out(e2.c0, 2); T.out(e2.c1, 3);
+    d.optimise();
+    return d;
+}
+
+// The same for a decoded G1 point: (beta x, y) = [-z^2]P with beta the cube root of unity xi^((p^2-1)/3) (the test
+// of the same note and library).  [z^2]P as [|x|]([|x|]P), the second pass adding a projective point; in projective
+// coordinates beta x Z = X and y Z = -Y.  gin: P affine (2); gout: the two differences (2).
+Dag build_g1_subgroup() {
+    Dag d;
+    d.n_in = 2; d.n_out = 2;
+    Tower T(d);
+    const SFp px = T.in(0), py = T.in(1);
+    struct Pt { SFp X, Y, Z; };
+    auto dbl = [&](const Pt& p) {  // (3 b = 12; s = 3 Z^2 as above)
+        SFp t0 = T.mul(p.Y, p.Y);
+        SFp z8 = T.lin({{t0, 8}});
+        SFp t1 = T.mul(p.Y, p.Z);
+        SFp s = T.lin({{T.mul(p.Z, p.Z), 3}});
+        SFp xy = T.mul(p.X, p.Y);
+        SFp z3 = T.mul(t1, z8);
+        SFp t0m = T.lin({{t0, 1}, {s, -12}});
+        SFp y3{T.dag().dot2(T.mat(T.lin({{s, 4}})).id, T.mat(z8).id, T.mat(t0m).id, T.mat(T.lin({{t0, 1}, {s, 4}})).id)};
+        SFp xo = T.lin({{T.mul(t0m, xy), 2}});
+        return Pt{xo, y3, z3};
+    };
+    auto add = [&](const Pt& p, const Pt& q) {
+        SFp t0 = T.mul(p.X, q.X), t1 = T.mul(p.Y, q.Y), t2 = T.mul(p.Z, q.Z);
+        SFp t3 = T.sub(T.mul(T.add(p.X, p.Y), T.add(q.X, q.Y)), T.add(t0, t1));
+        SFp t4 = T.sub(T.mul(T.add(p.Y, p.Z), T.add(q.Y, q.Z)), T.add(t1, t2));
+        SFp y3 = T.sub(T.mul(T.add(p.X, p.Z), T.add(q.X, q.Z)), T.add(t0, t2));
+        SFp x3 = T.lin({{t0, 3}});
+        t2 = T.lin({{t2, 12}});
+        SFp z3 = T.add(t1, t2);
+        t1 = T.sub(t1, t2);
+        y3 = T.lin({{y3, 12}});
+        SFp xo{T.dag().dot2(T.mat(t3).id, T.mat(t1).id, T.mat(t4).id, T.mat(y3).id, /*neg_d=*/true)};
+        SFp yo{T.dag().dot2(T.mat(t1).id, T.mat(z3).id, T.mat(y3).id, T.mat(x3).id)};
+        SFp zo{T.dag().dot2(T.mat(z3).id, T.mat(t4).id, T.mat(x3).id, T.mat(t3).id)};
+        return Pt{xo, yo, zo};
+    };
+    auto mul_x = [&](const Pt& base) {
+        Pt r = base;
+        for (int i = 62; i >= 0; i--) {
+            r = dbl(r);
+            if ((0xd201000000010000ull >> i) & 1ull) r = add(r, base);
+        }
+        return r;
+    };
+    const Pt r = mul_x(mul_x(Pt{px, py, SONE}));
+    const SFp beta = T.cst(C_FROB2_BASE + 1);
+    const SFp e1 = T.sub(T.mul(T.mul(beta, px), r.Z), r.X);
+    const SFp e2{T.dag().dot2(T.mat(py).id, T.mat(r.Z).id, T.mat(r.Y).id, T.cst(C_ONE).id)};
+    T.out(e1, 0); T.out(e2, 1);
+    d.optimise();
+    return d;
+}
+
 Dag build_ell() {
     Dag d;
     d.n_in = 20; d.n_out = 12;

@@ -713,7 +713,7 @@ def _bytes_array(encodings):
     return np.frombuffer(b"".join(encodings), dtype=np.uint8).reshape(len(encodings), -1)
 
 
-def test_compressed_points_and_aggregation(ctx):
+def test_compressed_points_and_aggregation(ctx, monkeypatch):
     """Wire format and aggregation against the big-integer oracle: every decoded limb, status byte,
     encoded byte and aggregate is compared; the device's endomorphism subgroup tests are checked
     against [r]P = O on curve points inside and outside the subgroup."""
@@ -741,9 +741,12 @@ def test_compressed_points_and_aggregation(ctx):
             outside.append(bytes(e))
         x += 1
     allenc = enc + bad + outside
-    for check in (True, False):
+    for check, form in ((True, None), (True, "0"), (False, None)):   # form "0": the subgroup test inside the decoder
+        if form is not None:
+            monkeypatch.setenv("BLS381_G1_SUBGROUP_PROGRAM", form)
         want = [PT.g1_decompress(e, check_subgroup=check) for e in allenc]
         out, status = ctx.g1_decompress_batch(_bytes_array(allenc), check_subgroup=check, return_status=True)
+        monkeypatch.delenv("BLS381_G1_SUBGROUP_PROGRAM", raising=False)
         assert status.tolist() == [s for s, _ in want]
         assert np.array_equal(out, H.g1_array([p for _, p in want]))
     assert [s for s, _ in [PT.g1_decompress(e) for e in outside]] == [PT.NOT_IN_SUBGROUP] * 3
@@ -772,11 +775,19 @@ def test_compressed_points_and_aggregation(ctx):
             off_curve2.append(bytes(e))
         x0 += 1
     allenc2 = enc2 + bad2 + off_curve2 + outside2
-    for check in (True, False):
+    for check, form in ((True, None), (True, "0"), (False, None)):   # form "0": the subgroup test inside the decoder
+        if form is not None:
+            monkeypatch.setenv("BLS381_G2_SUBGROUP_PROGRAM", form)
         want = [PT.g2_decompress(e, check_subgroup=check) for e in allenc2]
         out, status = ctx.g2_decompress_batch(_bytes_array(allenc2), check_subgroup=check, return_status=True)
+        monkeypatch.delenv("BLS381_G2_SUBGROUP_PROGRAM", raising=False)
         assert status.tolist() == [s for s, _ in want]
         assert np.array_equal(out, H.g2_array([q for _, q in want]))
+    # a batch that is not one wave: every eleventh point outside the subgroup
+    many = [outside2[i % 2] if i % 11 == 3 else enc2[i % (len(enc2) - 1)] for i in range(300)]
+    out, status = ctx.g2_decompress_batch(_bytes_array(many), return_status=True)
+    assert status.tolist() == [PT.NOT_IN_SUBGROUP if i % 11 == 3 else 0 for i in range(300)]
+    assert all(not out[i].any() for i in range(300) if i % 11 == 3)
     assert PT.g2_decompress(outside2[0])[0] == PT.NOT_IN_SUBGROUP and PT.g2_decompress(off_curve2[0])[0] == PT.NOT_ON_CURVE
 
     # ---- encode
@@ -883,7 +894,7 @@ def test_point_format_golden_vectors(ctx):
     assert st.tolist() == [4, 4]
 
 
-def test_signature_checks_from_bytes(ctx):
+def test_signature_checks_from_bytes(ctx, monkeypatch):
     """bls381_verify_batch against the oracle: decode with oracle/py/bls381_points.py, then
     native_pairing([pk, -G1], [msg, sig]) == 1 with the big-integer pairing."""
     import random
@@ -913,6 +924,17 @@ def test_signature_checks_from_bytes(ctx):
     # item 9: message point and signature both at infinity under a real key: the product would be empty (one);
     # a message point at infinity is rejected
     pks.append(pks[0]); msgs.append(PT.g2_compress(None)); sigs.append(PT.g2_compress(None))
+    # items 10, 11: a message point, then a signature, on the twist but outside the subgroup
+    x0 = 1
+    while True:
+        xx = (x0, 1)
+        if R.fq2_pow(R.fq2_add(R.fq2_mul(R.fq2_square(xx), xx), (4, 4)), (R.P * R.P - 1) // 2) == R.FQ2_ONE:
+            break
+        x0 += 1
+    e = bytearray((1).to_bytes(48, "big") + x0.to_bytes(48, "big")); e[0] |= 0x80
+    assert PT.g2_decompress(bytes(e))[0] == PT.NOT_IN_SUBGROUP
+    pks.append(pks[0]); msgs.append(bytes(e)); sigs.append(sigs[0])
+    pks.append(pks[0]); msgs.append(msgs[0]); sigs.append(bytes(e))
     verdict, status = ctx.verify_batch(_bytes_array(pks), _bytes_array(msgs), _bytes_array(sigs))
     want_v, want_s = [], []
     neg_g1 = R.g1_neg(R.G1_GEN)
@@ -926,10 +948,18 @@ def test_signature_checks_from_bytes(ctx):
         pairs = [(a, b) for a, b in pairs if a is not None and b is not None]
         want_v.append(1 if R.native_pairing([a for a, _ in pairs], [b for _, b in pairs]) == R.FQ12_ONE else 0)
     assert status.tolist() == want_s
-    assert verdict.tolist() == want_v == [1, 0, 1, 1, 0, 0, 0, 0, 1, 0]
+    assert verdict.tolist() == want_v == [1, 0, 1, 1, 0, 0, 0, 0, 1, 0, 0, 0]
+    assert status[10].tolist() == [0, PT.NOT_IN_SUBGROUP, 0] and status[11].tolist() == [0, 0, PT.NOT_IN_SUBGROUP]
+    # the same with the G2 subgroup tests inside the decoders (one lane per point) instead of the step program
+    monkeypatch.setenv("BLS381_G2_SUBGROUP_PROGRAM", "0")
+    monkeypatch.setenv("BLS381_G1_SUBGROUP_PROGRAM", "0")
+    v1, s1 = ctx.verify_batch(_bytes_array(pks), _bytes_array(msgs), _bytes_array(sigs))
+    monkeypatch.delenv("BLS381_G2_SUBGROUP_PROGRAM")
+    monkeypatch.delenv("BLS381_G1_SUBGROUP_PROGRAM")
+    assert v1.tolist() == want_v and s1.tolist() == want_s
     # without the subgroup test the off-subgroup key decodes, and its check fails in the pairing instead
     v2, s2 = ctx.verify_batch(_bytes_array(pks), _bytes_array(msgs), _bytes_array(sigs), check_subgroup=False)
-    assert s2[7].tolist() == [0, 0, 0] and v2.tolist() == want_v
+    assert s2[7].tolist() == [0, 0, 0] and s2[10].tolist() == [0, 0, 0] and v2.tolist() == want_v
 
 
 def test_new_entry_points_edge_sizes(ctx, CO):

@@ -131,6 +131,23 @@ def test_auxiliary_programs():
     q = R.g2_mul(R.G2_GEN, 77)
     got = run("g2prep", [q[0][0], q[0][1], q[1][0], q[1][1]])
     assert got == [x for cf in R.g2_prepare(q) for fq2 in cf for x in fq2]
+    # the G2 subgroup test psi(Q) = [z]Q as a program: four zeros for a point of the subgroup, and only for such a point
+    import bls381_points as PT
+    sub = lambda pt: run("g2sub", [pt[0][0], pt[0][1], pt[1][0], pt[1][1]])
+    assert sub(q) == [0, 0, 0, 0] and sub(R.g2_neg(R.G2_GEN)) == [0, 0, 0, 0]
+    x0 = 1
+    while R.fq2_pow(R.fq2_add(R.fq2_mul(R.fq2_square((x0, 1)), (x0, 1)), (4, 4)), (R.P * R.P - 1) // 2) != R.FQ2_ONE:
+        x0 += 1
+    e = bytearray((1).to_bytes(48, "big") + x0.to_bytes(48, "big")); e[0] |= 0x80
+    status, outside = PT.g2_decompress(bytes(e), check_subgroup=False)
+    assert status == PT.OK and PT.g2_decompress(bytes(e))[0] == PT.NOT_IN_SUBGROUP and any(sub(outside))
+    # ... and the G1 test (beta x, y) = [-z^2]P
+    sub1 = lambda pt: run("g1sub", [pt[0], pt[1]])
+    assert sub1(p) == [0, 0] and sub1(R.G1_GEN) == [0, 0]
+    x1 = 4
+    while R.fq_sqrt((x1 ** 3 + 4) % R.P) is None:
+        x1 += 1
+    assert any(sub1((x1, R.fq_sqrt((x1 ** 3 + 4) % R.P))))
     # easy part through the split inverse
     mid = S.run_program(S.get_program("fe1"), [M(v) for v in fa])
     mid[0] = M(R.fq_inv(F(mid[0])))
