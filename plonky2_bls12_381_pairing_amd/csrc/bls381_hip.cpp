@@ -198,6 +198,10 @@ static std::string base_name(const std::string& which) { return which.substr(0, 
 static void program_geometry(const bls381_ctx* c, const std::string& which, int& K, int& slots) {
     K = c->K; slots = c->lds_slots;
     if (c->auto_geometry && (which == "miller2" || which == "miller2s" || which.find("@16") != std::string::npos)) { K = 16; slots = default_slots(16); }
+    // Four lanes per item for the subgroup-test programs on large batches: a doubling of a point is two levels of at most
+    // four (G1) or eight (G2) products with a few sums between them, which leave half the lanes of an eight-lane group
+    // idle in most steps; sixteen items per wave instead of eight use them (G1: 666 steps either way; G2: 535 against 356).
+    else if (c->auto_geometry && which.find("@4") != std::string::npos) { K = 4; slots = default_slots(4); }
 }
 
 // Synthetic programs for timing one step kind in isolation: 1,000 identical steps with every lane
@@ -410,6 +414,7 @@ static int run_program_on(bls381_ctx* c, const std::string& which, const void* g
     const DevProgram& p = it->second;
     hipError_t e;
     switch (p.host.K) {
+        case 4: e = launch_vm_kt<4, TAG_AUX>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)gtmp, n, npad); break;  // (the subgroup tests only)
         case 6: e = launch_vm_k<6>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)gtmp, n, npad); break;
         case 8: e = launch_vm_k<8>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)gtmp, n, npad); break;
         case 9: e = launch_vm_k<9>(c, p, (const uint4*)gin, (uint4*)gout, (uint4*)gtmp, n, npad); break;
@@ -422,7 +427,8 @@ static int run_program_on(bls381_ctx* c, const std::string& which, const void* g
 static size_t spill_bytes(const DevProgram& p, int npad) { return (size_t)std::max(1, p.host.n_tmp_slots) * 56 * npad; }
 static int run_program(bls381_ctx* c, const char* which_c, const void* gin, void* gout, int n, int npad) {
     std::string which = which_c;
-    if (c->auto_geometry && n <= SMALL_BATCH && which != "miller2" && which != "miller2s" && which.rfind("t_", 0) != 0) {
+    if (c->auto_geometry && n <= SMALL_BATCH && which != "miller2" && which != "miller2s" && which.rfind("t_", 0) != 0 &&
+        which.find('@') == std::string::npos) {
         which += "@16";
         if (!c->progs.count(which)) {
             int rc = upload_program(c, which);
@@ -1548,7 +1554,7 @@ extern "C" int bls381_debug_program(const char* which, int K, int lds_slots, uin
                                     size_t capacity_steps, uint32_t info[8]) {
     if (!which || !info) return fail(BLS381_ERR_INVALID, "NULL argument");
     if (K == 0) K = 8;
-    if (!valid_k(K)) return fail(BLS381_ERR_INVALID, "bad K");
+    if (!valid_k(K) && K != 4) return fail(BLS381_ERR_INVALID, "bad K");  // (4: the width of the G1 subgroup-test program for large batches)
     if (lds_slots == 0) lds_slots = default_slots(K);
     Program p;
     try {
@@ -1847,8 +1853,7 @@ extern "C" int bls381_fq6_inverse_limbs_batch(bls381_ctx* c, const uint32_t* x, 
 static const size_t MAX_POINTS = (size_t)1 << 22;
 // The order-r test of decoded points as a step program over lane groups (build_g2_subgroup, build_g1_subgroup) instead
 // of one lane per point inside the decoder.  G2: 65,536 points take 2.3 ms this way against 5.0 ms, one point 0.3 ms
-// against 3 ms.  G1 (twice the doublings, in Fq: half of a lane group's lanes idle): only for batches small enough
-// that latency is what counts.
+// against 3 ms.  Batches of more than SMALL_BATCH points run the programs at four lanes per point (program_geometry).
 // pts_dev: n affine points (Montgomery limbs, zero where the decoder rejected the encoding); status_dev: the decoder's
 // status bytes, where ST_OK becomes ST_NOT_IN_SUBGROUP for the points that fail (and the point zero, as the decoder
 // leaves every point it rejects).  Runs on the context's stream and returns with it synchronised.
@@ -1858,12 +1863,17 @@ static bool env_on(const char* name) {
     return !(e && atoi(e) == 0);
 }
 static bool g2_subgroup_as_program() { return env_on("BLS381_G2_SUBGROUP_PROGRAM"); }
-static bool g1_subgroup_as_program(size_t n) { return n <= (size_t)SMALL_BATCH && env_on("BLS381_G1_SUBGROUP_PROGRAM"); }
-static int subgroup_dev(bls381_ctx* c, const char* prog, int fq, u32* pts_dev, size_t n, uint8_t* status_dev) {
+// (the G1 program beats one lane per key on a large batch only at four lanes per key, which contexts with a caller-chosen
+// geometry do not use)
+static bool g1_subgroup_as_program(const bls381_ctx* c, size_t n) {
+    return (n <= (size_t)SMALL_BATCH || c->auto_geometry) && env_on("BLS381_G1_SUBGROUP_PROGRAM");
+}
+static int subgroup_dev(bls381_ctx* c, const char* prog_base, int fq, u32* pts_dev, size_t n, uint8_t* status_dev) {
     if (n == 0) return 0;
     DevBuf& diff = c->vbuf[8];
     HIPCHK(diff.ensure(n * 2 * fq * 48));
-    int rc = simple_dev_locked(c, prog, {{pts_dev, 2 * fq}}, n, diff.p, 2 * fq, CHUNK);
+    const std::string prog = std::string(prog_base) + (c->auto_geometry && n > (size_t)SMALL_BATCH ? "@4" : "");
+    int rc = simple_dev_locked(c, prog.c_str(), {{pts_dev, 2 * fq}}, n, diff.p, 2 * fq, CHUNK);
     if (rc) return rc;
     hipLaunchKernelGGL(pts::subgroup_status_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, (const u32*)diff.p,
                        2 * fq * 12, (int)n, status_dev, pts_dev, 2 * fq * 12);
@@ -1899,7 +1909,7 @@ static int decompress_host(bls381_ctx* c, const uint8_t* in, size_t n, size_t by
 extern "C" int bls381_g1_decompress_batch(bls381_ctx* c, const uint8_t* in, size_t n, int check_subgroup, uint64_t* g1,
                                           uint8_t* status) {
     CTX_GUARD(c);
-    const bool as_program = check_subgroup && g1_subgroup_as_program(n);
+    const bool as_program = check_subgroup && g1_subgroup_as_program(c, n);
     return decompress_host(c, in, n, 48, 2, g1, status, [&](const uint8_t* d, int m, u32* o, uint8_t* s) {
         hipLaunchKernelGGL(pts::g1_decompress_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, d, m, as_program ? 0 : check_subgroup, o, s);
         HIPCHK(hipGetLastError());
@@ -2033,7 +2043,7 @@ extern "C" int bls381_verify_batch(bls381_ctx* c, const uint8_t* pk48, const uin
     // on three streams and share the GPU.
     uint8_t* bytes = (uint8_t*)v[B_BYTES].p;
     HIPCHK(hipMemcpyAsync(bytes, pk48, n * 48, hipMemcpyHostToDevice, c->copy_stream));
-    const bool test_keys = check_subgroup & BLS381_CHECK_KEYS, keys_as_program = test_keys && g1_subgroup_as_program(n);
+    const bool test_keys = check_subgroup & BLS381_CHECK_KEYS, keys_as_program = test_keys && g1_subgroup_as_program(c, n);
     hipLaunchKernelGGL(pts::g1_decompress_kernel, grid, block, 0, c->copy_stream, (const uint8_t*)bytes, m,
                        (test_keys && !keys_as_program) ? 1 : 0, (u32*)v[B_G1A].p, st);
     HIPCHK(hipEventRecord(c->pipe_ev[0], c->copy_stream));
@@ -2128,7 +2138,7 @@ extern "C" int bls381_fast_aggregate_verify_batch(bls381_ctx* c, const uint8_t* 
     // Keys whose subgroup tests run inside the decoder (one lane per key: milliseconds) are decoded on the third stream,
     // behind the signature, while this stream takes the two G2 points through the subgroup-test program; otherwise on
     // this stream, beside the two G2 decoders.
-    const bool test_keys = check_subgroup & BLS381_CHECK_KEYS, keys_as_program = test_keys && g1_subgroup_as_program(n);
+    const bool test_keys = check_subgroup & BLS381_CHECK_KEYS, keys_as_program = test_keys && g1_subgroup_as_program(c, n);
     hipStream_t key_stream = (test_keys && !keys_as_program) ? c->aux_stream : c->stream;
     HIPCHK(hipMemcpyAsync(bytes, pk48, n * 48, hipMemcpyHostToDevice, key_stream));
     hipLaunchKernelGGL(pts::g1_decompress_kernel, dim3((unsigned)((n + 63) / 64)), block, 0, key_stream, (const uint8_t*)bytes,

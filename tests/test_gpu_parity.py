@@ -750,6 +750,11 @@ def test_compressed_points_and_aggregation(ctx, monkeypatch):
         assert status.tolist() == [s for s, _ in want]
         assert np.array_equal(out, H.g1_array([p for _, p in want]))
     assert [s for s, _ in [PT.g1_decompress(e) for e in outside]] == [PT.NOT_IN_SUBGROUP] * 3
+    for count in (300, 8300):   # (as for G2 below: 16 and 4 lanes per point)
+        many = [outside[i % 3] if i % 11 == 3 else enc[i % (len(enc) - 1)] for i in range(count)]
+        out, status = ctx.g1_decompress_batch(_bytes_array(many), return_status=True)
+        assert status.tolist() == [PT.NOT_IN_SUBGROUP if i % 11 == 3 else 0 for i in range(count)]
+        assert all(not out[i].any() for i in range(count) if i % 11 == 3)
     with pytest.raises(Exception, match="subgroup"):
         ctx.g1_decompress_batch(_bytes_array(outside))
     good, status = ctx.g1_decompress_batch(_bytes_array(enc))
@@ -783,11 +788,15 @@ def test_compressed_points_and_aggregation(ctx, monkeypatch):
         monkeypatch.delenv("BLS381_G2_SUBGROUP_PROGRAM", raising=False)
         assert status.tolist() == [s for s, _ in want]
         assert np.array_equal(out, H.g2_array([q for _, q in want]))
-    # a batch that is not one wave: every eleventh point outside the subgroup
-    many = [outside2[i % 2] if i % 11 == 3 else enc2[i % (len(enc2) - 1)] for i in range(300)]
-    out, status = ctx.g2_decompress_batch(_bytes_array(many), return_status=True)
-    assert status.tolist() == [PT.NOT_IN_SUBGROUP if i % 11 == 3 else 0 for i in range(300)]
-    assert all(not out[i].any() for i in range(300) if i % 11 == 3)
+    # batches that are not one wave, every eleventh point outside the subgroup: 300 points (16 lanes per point) and
+    # 8,300 (past the size from which the test program runs at four lanes per point)
+    for count in (300, 8300):
+        many = [outside2[i % 2] if i % 11 == 3 else enc2[i % (len(enc2) - 1)] for i in range(count)]
+        out, status = ctx.g2_decompress_batch(_bytes_array(many), return_status=True)
+        assert status.tolist() == [PT.NOT_IN_SUBGROUP if i % 11 == 3 else 0 for i in range(count)]
+        assert all(not out[i].any() for i in range(count) if i % 11 == 3)
+        expected = H.g2_array(g2s[:-1])
+        assert all(np.array_equal(out[i], expected[i % len(expected)]) for i in range(count) if i % 11 != 3)
     assert PT.g2_decompress(outside2[0])[0] == PT.NOT_IN_SUBGROUP and PT.g2_decompress(off_curve2[0])[0] == PT.NOT_ON_CURVE
 
     # ---- encode
