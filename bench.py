@@ -15,6 +15,8 @@ Prints ONE JSON line on rank 0 with the fields the driver expects plus
 and, outside the timed region (rank 0, one GPU; --no-extras leaves them out), the other configured workloads:
   multi_pairing_513  the 512-key aggregate check (513 pairs -> one Fq12 -> final exponentiation -> is one), valid and
                      forged, latency per call
+  signature_checks_65536  65,536 signature checks from compressed bytes (decoders, subgroup tests, two-pair pairing),
+                     with and without the subgroup tests; one signature in eight forged
   shard_1m           one GPU's shard of the 8,388,608-pair configuration: 1,048,576 pairings on device pointers
   witness            the pairing circuit's witness trace: 256 proofs through host pointers and 16,384 proofs left in
                      HBM, proofs/s, fractions of the multiply-accumulate and HBM rooflines, every row of one proof
@@ -95,6 +97,40 @@ def bench_multi_pairing(np, H, ctx):
         ctx.native_pairing(g1, g2)
     return {"pairs": 513, "ms_per_check": (time.perf_counter() - t0) / reps * 1e3, "is_one": True, "forged_is_one": False,
             "what": "bls381_multi_pairing on host pointers: 513 Miller loops, in-kernel product tree, one final exponentiation"}
+
+
+def bench_signature_checks(np, H, ctx):
+    """65,536 signature checks from compressed bytes (bls381_verify_batch: three decoders, the subgroup tests as step
+    programs, the two-pair pairing, a verdict byte per item).  Eight distinct (key, message point, signature) triples
+    from the Python oracle, tiled; one triple in eight carries a forged signature."""
+    import random
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "py"))
+    import bls381_points as PT
+    R = H.R
+    rng = random.Random(65536)
+    pk, mg, sg = [], [], []
+    for i in range(8):
+        sk, h = rng.randrange(1, R.R_ORDER), rng.randrange(1, R.R_ORDER)
+        hm = R.g2_mul(R.G2_GEN, h)
+        pk.append(PT.g1_compress(R.g1_mul(R.G1_GEN, sk)))
+        mg.append(PT.g2_compress(hm))
+        sg.append(PT.g2_compress(R.g2_mul(hm, sk if i != 5 else sk + 1)))
+    n = 65536
+    tile = lambda enc, w: np.tile(np.frombuffer(b"".join(enc), dtype=np.uint8).reshape(8, w), (n // 8, 1))
+    bpk, bmg, bsg = tile(pk, 48), tile(mg, 96), tile(sg, 96)
+    out = {"items": n, "what": "bls381_verify_batch on host pointers: 48 + 96 + 96 bytes in, one verdict byte out per item"}
+    for label, mask in (("all_subgroup_tests", 7), ("no_subgroup_tests", 0)):
+        verdict, _ = ctx.verify_batch(bpk, bmg, bsg, check_subgroup=mask)
+        if verdict.tolist() != [0 if i % 8 == 5 else 1 for i in range(n)]:
+            raise SystemExit("signature checks from bytes give wrong verdicts")
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ctx.verify_batch(bpk, bmg, bsg, check_subgroup=mask)
+            best = min(best, time.perf_counter() - t0)
+        out[label] = {"ms": best * 1e3, "checks_per_s": n / best}
+    out["verdicts"] = "57,344 valid and 8,192 forged signatures told apart in both runs"
+    return out
 
 
 def bench_shard(np, torch, _lib, ctx, dev, g1, g2, d_out_batch):
@@ -443,6 +479,7 @@ def main():
         if world == 1 and not args.no_extras:
             t_extra = time.perf_counter()
             res["multi_pairing_513"] = bench_multi_pairing(np, H, ctx)
+            res["signature_checks_65536"] = bench_signature_checks(np, H, ctx)
             res["shard_1m"] = bench_shard(np, torch, _lib, ctx, dev, g1, g2, d_out)
             res["witness"] = bench_witness(np, torch, _lib, H, B, ctx, dev)
             res["extras_s"] = time.perf_counter() - t_extra
