@@ -148,6 +148,10 @@ def test_auxiliary_programs():
     while R.fq_sqrt((x1 ** 3 + 4) % R.P) is None:
         x1 += 1
     assert any(sub1((x1, R.fq_sqrt((x1 ** 3 + 4) % R.P))))
+    # the schedules for four lanes per point (large batches run the two tests that way) give the same answers
+    run4 = lambda name, gin: [F(x) for x in S.run_program(S.get_program(name, 4, 0), [M(v) for v in gin])]
+    assert run4("g2sub", [q[0][0], q[0][1], q[1][0], q[1][1]]) == [0, 0, 0, 0] and run4("g1sub", [p[0], p[1]]) == [0, 0]
+    assert run4("g2sub", [outside[0][0], outside[0][1], outside[1][0], outside[1][1]]) == sub(outside)
     # easy part through the split inverse
     mid = S.run_program(S.get_program("fe1"), [M(v) for v in fa])
     mid[0] = M(R.fq_inv(F(mid[0])))
