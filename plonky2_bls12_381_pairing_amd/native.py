@@ -455,15 +455,20 @@ class Context:
                                                      _p8(verdict), _p8(status)))
         return verdict, status
 
-    def pairing_witness_batch(self, g1, g2):
+    def pairing_witness_batch(self, g1, g2, out=None):
+        """The witness trace of n proofs, (n, rows, 12) u32.  `out`: an array of that shape to write into (a caller that
+        produces traces repeatedly keeps one: 6.8 MB per proof of fresh memory are page faults on every call)."""
         g1, g2 = _arr64(g1, 12), _arr64(g2, 24)
         n = g1.shape[0]
         if g2.shape[0] != n:
             raise ValueError("g1 and g2 must have one row per proof")
         rows = lib.bls381_pairing_witness_rows()
-        trace = np.empty((n, rows, 12), dtype=np.uint32)
-        check(lib.bls381_pairing_witness_batch(self._h, _p64(g1), _p64(g2), n, _p32(trace)))
-        return trace
+        if out is None:
+            out = np.empty((n, rows, 12), dtype=np.uint32)
+        elif out.shape != (n, rows, 12) or out.dtype != np.uint32 or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous uint32 array of shape (n, rows, 12)")
+        check(lib.bls381_pairing_witness_batch(self._h, _p64(g1), _p64(g2), n, _p32(out)))
+        return out
 
     def pairing_witness_aux_batch(self, g1, g2, want=(True, True, True)):
         """The trace plus the gadgets' auxiliary values: (trace, mul_quot (n, mul rows, 24), carry (n, rows),
