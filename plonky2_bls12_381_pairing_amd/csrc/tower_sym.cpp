@@ -201,9 +201,9 @@ SFq2 Tower::sqr(const SFq2& a) {
 // ------------------------------------------------------------------ Fq6
 SFq6 Tower::mul(const SFq6& a, const SFq6& b) {
     if (lazy_) return reduce(umul(a, b));
-    bool sparse = is_zero(a.c0) || is_zero(a.c1) || is_zero(a.c2) || is_zero(b.c0) || is_zero(b.c1) ||
-                  is_zero(b.c2);
-    if (sparse) {
+    const int zeros = is_zero(a.c0) + is_zero(a.c1) + is_zero(a.c2) + is_zero(b.c0) + is_zero(b.c1) + is_zero(b.c2);
+    // (one zero component in all: Karatsuba below still saves a product, five against the schoolbook's six)
+    if (zeros > 1) {
         // schoolbook with zero propagation
         SFq2 p00 = mul(a.c0, b.c0), p01 = mul(a.c0, b.c1), p02 = mul(a.c0, b.c2);
         SFq2 p10 = mul(a.c1, b.c0), p11 = mul(a.c1, b.c1), p12 = mul(a.c1, b.c2);
@@ -574,11 +574,31 @@ Dag build_miller_two_pairs(bool scaled) {
         qx[j] = SFq2{T.in(b + 2), T.in(b + 3)}; qy[j] = SFq2{T.in(b + 4), T.in(b + 5)};
         r[j] = Tower::G2Proj{qx[j], qy[j], T.one2()};
     }
+    // The two lines of a step are multiplied with each other first (two elements with three of six coefficients: six
+    // Fq2 products by Karatsuba) and f by their product (five of six coefficients: 17), 23 Fq2 products where two sparse
+    // products of f cost 26.  The value of f is the same field element either way.
+    auto both = [&](const Tower::EllCoeff& a, const Tower::EllCoeff& b) {
+        const SFq2 c0 = a.c0, c1 = T.mul_fp(a.c1, px[0]), c4 = T.mul_fp(a.c2, py[0]);
+        const SFq2 d0 = b.c0, d1 = T.mul_fp(b.c1, px[1]), d4 = T.mul_fp(b.c2, py[1]);
+        const SFq2 p00 = T.mul(c0, d0), p11 = T.mul(c1, d1), p44 = T.mul(c4, d4);
+        const SFq2 p01 = T.mul(T.add(c0, c1), T.add(d0, d1)), p04 = T.mul(T.add(c0, c4), T.add(d0, d4));
+        const SFq2 p14 = T.mul(T.add(c1, c4), T.add(d1, d4));
+        // (c0 + c1 v + c4 v w)(d0 + d1 v + d4 v w), w^2 = v, v^3 = xi
+        const SFq12 lines{{T.add(p00, T.mul_xi(p44)), T.lin2({{p01, 1}, {p00, -1}, {p11, -1}}), p11},
+                          {T.zero2(), T.lin2({{p04, 1}, {p00, -1}, {p44, -1}}), T.lin2({{p14, 1}, {p11, -1}, {p44, -1}})}};
+        f = T.mul(f, lines);
+    };
     for (int i = 62; i >= 0; i--) {
         f = T.sqr(f);
-        for (int j = 0; j < 2; j++) f = T.ell(f, scaled ? T.g2_double_scaled(r[j]) : T.g2_double(r[j], T.cst(C_TWO_INV)), px[j], py[j]);
-        if ((BLS381_X >> i) & 1)
-            for (int j = 0; j < 2; j++) f = T.ell(f, T.g2_add(r[j], qx[j], qy[j]), px[j], py[j]);
+        {
+            const Tower::EllCoeff a = scaled ? T.g2_double_scaled(r[0]) : T.g2_double(r[0], T.cst(C_TWO_INV));
+            const Tower::EllCoeff b = scaled ? T.g2_double_scaled(r[1]) : T.g2_double(r[1], T.cst(C_TWO_INV));
+            both(a, b);
+        }
+        if ((BLS381_X >> i) & 1) {
+            const Tower::EllCoeff a = T.g2_add(r[0], qx[0], qy[0]), b = T.g2_add(r[1], qx[1], qy[1]);
+            both(a, b);
+        }
     }
     f = T.conj(f);
     T.out12(f, 0);
